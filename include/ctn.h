@@ -1,0 +1,312 @@
+/*
+ * ctn.h — C ABI of libctn_hip.so: gfx950 (MI355X) kernels for the Conv-TasNet
+ * training hot path.
+ *
+ * The reference (SaisumanaP/speech) has no FFI of its own for this path: every
+ * operation is a stock torch.nn call.  Each entry point below therefore cites the
+ * reference Python call site(s) whose arithmetic it replaces (paths relative to
+ * the reference root).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer to fp32 unless typed otherwise.
+ *  - Activations are (batch, C, ld) row-major with `T` valid time steps per row,
+ *    ld >= T, ld % 4 == 0, rows 16-byte aligned.  Columns [T, ld) are padding:
+ *    never read as data, may be overwritten with garbage.
+ *  - The caller owns every buffer (inputs, outputs, workspaces, accumulators).
+ *    The library never allocates, frees or synchronises; every call only enqueues
+ *    kernels on `stream` (a hipStream_t).
+ *  - Accumulator outputs (documented "+=") must be zeroed by the caller.
+ *  - Return value: 0 on success, negative CTN_ERR_* otherwise;
+ *    ctn_last_error() gives the message of the calling thread's last failure.
+ *
+ * Layer-norm statistics ("stat" arrays).  Both norms are expressed as
+ *      n = (u - mean) * rstd * gamma[c] + beta[c]
+ *  with mean/rstd indexed [b * sb + t * st]:
+ *      gLN (GlobalLayerNorm, src/modules/norm.py:11-29): one value per sample, sb = 1, st = 0,
+ *          rstd = 1/sqrt(var + eps);
+ *      cLN (CumulativeLayerNorm1d, src/modules/norm.py:42-95): one value per frame, sb = ld_t, st = 1,
+ *          rstd = 1/(sqrt(var) + eps)   (eps outside the root, norm.py:90).
+ *  The backward of either norm is
+ *      du = g * rstd + c1 + (u - mean) * c2,   g = gamma[c] * dn,
+ *  with c1/c2 indexed like mean/rstd (ctn_gln_bwd_coefs / ctn_cln_bwd_coefs).
+ */
+#ifndef CTN_H
+#define CTN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTN_OK 0
+#define CTN_ERR_ARG (-1)     /* bad shape / alignment / null pointer */
+#define CTN_ERR_LAUNCH (-2)  /* hipLaunchKernel reported an error */
+
+/* operand transform flags (GEMM operands, norm kernels) */
+#define CTN_XF_PRELU 1    /* u = x > 0 ? x : alpha * x            (nn.PReLU, src/models/tdcn.py:119,184) */
+#define CTN_XF_NORM 2     /* n = (u - mean) * rstd * gamma + beta (src/modules/norm.py:27,90) */
+#define CTN_XF_NORMBWD 4  /* dy = (gamma*X*rstd + c1 + (prelu(X2)-mean)*c2) * (X2 > 0 ? 1 : alpha) */
+
+/* GEMM epilogue modes */
+#define CTN_EPI_STORE 0      /* Y = acc + bias */
+#define CTN_EPI_STATS 1      /* STORE, plus sums of prelu(Y, ealpha) and its square: esums (gLN) or ecol (cLN) */
+#define CTN_EPI_HEADS 2      /* rows < Mo: Y = acc + bias + R ; rows >= Mo: Y2 (+)= acc + bias2 */
+#define CTN_EPI_SIGMOID 3    /* Y = sigmoid(acc + bias) */
+#define CTN_EPI_PRELUBWD 4   /* Y = acc * (E > 0 ? 1 : ealpha); esums[0] += sum acc * min(E, 0) */
+#define CTN_EPI_NORMBWD 5    /* Y = acc; norm-backward sums of g = egamma*acc and g*xhat(E): esums / ecol */
+#define CTN_EPI_ADD 6        /* Y = acc + bias + (R ? R : 0) */
+
+const char* ctn_version(void);
+const char* ctn_last_error(void);
+/* sizeof() of the argument structs below, for bindings to check their mirror of this header */
+int ctn_sizeof_gemm_nn_args(void);
+int ctn_sizeof_gemm_nt_args(void);
+int ctn_sizeof_dw_fwd_args(void);
+int ctn_sizeof_dw_bwd_args(void);
+
+/* dst[k * ldd + coff + m] = src[m * K + k]  (m < M, k < K).  Lays a Conv1d(kernel_size=1) weight
+ * (M_out, K_in) out k-major for ctn_gemm_nn. */
+int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64_t coff, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pointwise (1x1) convolution as a batched GEMM on f32 MFMA:  Y[b] = A^T-layout(W) . xform(X[b])
+ * Replaces nn.Conv1d(kernel_size=1) at src/models/conv_tasnet.py:335,341 (:371,:374) and
+ * src/models/tdcn.py:86,173,175 (:116,:190,:194), forward and input-gradient, with the PReLU /
+ * layer-norm / residual / skip-sum / sigmoid neighbours of those calls fused into operand load
+ * and epilogue.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t M, T, K, batch;           /* Y is (batch, M, T); contraction length K */
+    /* A, k-major: element (k, m) at A[k*lda + m] for k < K1 else A2[(k-K1)*lda2 + m]. K1 = K if unsplit */
+    const float* A;  int64_t lda;
+    const float* A2; int64_t lda2;
+    int32_t K1;
+    int32_t xflags;                   /* CTN_XF_* applied to X on load */
+    const float* bias;                /* [M] (rows < Mo in HEADS) or NULL */
+    const float* bias2;               /* HEADS: [M - Mo] */
+    /* X (batch, K, ldx): rows k < K1 from X, k >= K1 from Xb */
+    const float* X;  int64_t ldx,  xbs;
+    const float* Xb; int64_t ldxb, xbbs;
+    const float* X2; int64_t ldx2, x2bs;   /* NORMBWD: pre-activation tensor, row k */
+    const float* alpha;               /* device scalar (PRELU / NORMBWD) */
+    const float* mean; const float* rstd; const float* c1; const float* c2;
+    int64_t ssb, sst;                 /* stat index = b*ssb + t*sst */
+    const float* gamma; const float* beta;   /* [K] */
+    float* Y; int64_t ldy, ybs;
+    int32_t emode;
+    int32_t Mo;                       /* HEADS split row */
+    const float* R; int64_t ldr, rbs; /* residual (HEADS rows < Mo, ADD) */
+    float* Y2; int64_t ldy2, y2bs;    /* HEADS rows >= Mo */
+    int32_t accumulate;               /* HEADS: Y2 += instead of = */
+    int32_t pad0;
+    const float* ealpha;              /* STATS / PRELUBWD / NORMBWD slope (NULL = 1, i.e. no PReLU) */
+    double* esums;                    /* [batch][2] (+=), PRELUBWD: [1] */
+    float* ecol; int64_t ecol_bs, ecol_ld;   /* cLN: [batch][2][ecol_ld] column sums (+=) */
+    const float* E; int64_t lde, ebs; /* epilogue input (batch, M, lde) */
+    const float* emean; const float* erstd; int64_t essb, esst;
+    const float* egamma;              /* [M] */
+} ctn_gemm_nn_args;
+
+int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient of a 1x1 convolution:  C[m][n] += sum_b sum_t xformA(A)[b][m][t] * xformB(B)[b][n][t]
+ * (the weight-gradient half of autograd for the nn.Conv1d calls listed above), split over
+ * (batch, time chunks) with fp32 atomic accumulation.  Optional fused reductions of the A operand:
+ * bias gradient (row sums) and the PReLU-slope gradient of the NORMBWD transform.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t M, N, T, batch;
+    const float* A;  int64_t lda,  abs_;      /* rows m < M1 */
+    const float* Ab; int64_t ldab, abbs;      /* rows m >= M1 */
+    int32_t M1;
+    int32_t aflags;                           /* 0 or CTN_XF_NORMBWD */
+    const float* A2; int64_t lda2, a2bs;      /* NORMBWD pre-activation */
+    const float* a_alpha;
+    const float* a_mean; const float* a_rstd; const float* a_c1; const float* a_c2;
+    int64_t a_ssb, a_sst;
+    const float* a_gamma;
+    float* a_rowsum;  /* [M1]     += sum_t A'[m][t]      (NULL to skip) */
+    float* a_rowsum2; /* [M - M1] */
+    double* a_dalpha; /* NORMBWD: += sum du * min(y, 0)  (NULL to skip) */
+    const float* B; int64_t ldb, bbs;
+    int32_t bflags;                           /* CTN_XF_PRELU | CTN_XF_NORM */
+    int32_t kchunk;                           /* time steps per block, multiple of 32 */
+    const float* b_alpha;
+    const float* b_mean; const float* b_rstd; int64_t b_ssb, b_sst;
+    const float* b_gamma; const float* b_beta;
+    float* C;  int64_t ldc;                   /* rows m < M1  (+=) */
+    float* C2; int64_t ldc2;                  /* rows m >= M1 (+=) */
+} ctn_gemm_nt_args;
+
+int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layer-norm statistics (src/modules/norm.py:18 nn.GroupNorm(1, C, eps); :78-90 cumulative form)
+ * ------------------------------------------------------------------------------------------- */
+/* sums[b][0] += sum prelu(x), sums[b][1] += sum prelu(x)^2 over (C, T)  [gln]   or
+ * col[b][0][t] += sum_c prelu(x), col[b][1][t] += sum_c prelu(x)^2     [cln]; alpha NULL = no PReLU */
+int ctn_norm_stats(const float* x, int batch, int C, int T, int64_t ld, const float* alpha,
+                   double* sums, float* col, int64_t col_ld, void* stream);
+/* gLN: mean = S1/count, rstd = 1/sqrt(S2/count - mean^2 + eps), count = C*T */
+int ctn_gln_finalize(const double* sums, int batch, double count, float eps, float* mean, float* rstd,
+                     void* stream);
+/* cLN: prefix sums over t of the column sums, divided by C*(t+1); rstd = 1/(sqrt(var)+eps) */
+int ctn_cln_finalize(const float* col, int batch, int C, int T, int64_t col_ld, float eps, float* mean,
+                     float* rstd, int64_t stat_ld, void* stream);
+/* y = (prelu(x) - mean) * rstd * gamma + beta */
+int ctn_norm_apply(const float* x, int batch, int C, int T, int64_t ld, const float* alpha,
+                   const float* mean, const float* rstd, int64_t ssb, int64_t sst, const float* gamma,
+                   const float* beta, float* y, int64_t ldy, void* stream);
+/* reductions of the norm backward: with g = gamma*dn, xhat = (prelu(x)-mean)*rstd:
+ *   gln: sums[b][0] += sum g, sums[b][1] += sum g*xhat ; cln: the same per frame into col;
+ *   dgamma[c] += sum dn*xhat, dbeta[c] += sum dn */
+int ctn_norm_bwd_reduce(const float* dn, int64_t lddn, const float* x, int64_t ld, int batch, int C, int T,
+                        const float* alpha, const float* mean, const float* rstd, int64_t ssb, int64_t sst,
+                        const float* gamma, double* sums, float* col, int64_t col_ld, float* dgamma,
+                        float* dbeta, void* stream);
+/* gLN: c1 = -rstd*S1/count, c2 = -rstd^2*S2/count */
+int ctn_gln_bwd_coefs(const double* sums, const float* rstd, int batch, double count, float* c1, float* c2,
+                      void* stream);
+/* cLN: reverse prefix sums of the per-frame mean/variance gradients (derivation in csrc/ctn_norm.hip) */
+int ctn_cln_bwd_coefs(const float* col, int64_t col_ld, const float* mean, const float* rstd, int64_t stat_ld,
+                      int batch, int C, int T, float eps, float* c1, float* c2, void* stream);
+/* dx = (gamma*dn*rstd + c1 + (prelu(x)-mean)*c2) * (x > 0 ? 1 : alpha);  dalpha += sum du*min(x,0) */
+int ctn_norm_bwd_apply(const float* dn, int64_t lddn, const float* x, int64_t ld, int batch, int C, int T,
+                       const float* alpha, const float* mean, const float* rstd, const float* c1,
+                       const float* c2, int64_t ssb, int64_t sst, const float* gamma, float* dx, int64_t lddx,
+                       double* dalpha, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused  [PReLU -> layer norm] -> zero-pad -> dilated depthwise Conv1d -> [PReLU statistics]
+ * Replaces src/models/tdcn.py:119-132 (PReLU, norm, F.pad of the hidden tensor) and :181-187
+ * (depthwise nn.Conv1d(groups=H, dilation=d, bias=True), PReLU, norm statistics); with
+ * xflags = 0 and out_alpha = NULL it is the plain depthwise conv of src/modules/conv.py:22,26.
+ * The input transform is applied on load, so the normalised tensor never reaches HBM; the output
+ * is the pre-activation y2 and the statistics are those of prelu(y2, out_alpha).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, C, T, P;           /* P taps */
+    int32_t dilation, pad_left;       /* input index of tap k for output t: t + k*dilation - pad_left */
+    int32_t xflags;                   /* CTN_XF_PRELU | CTN_XF_NORM on the input */
+    int32_t cln;                      /* 0: esums (gLN) ; 1: ecol (cLN) */
+    const float* x; int64_t ldx, xbs;
+    const float* alpha_in;
+    const float* mean; const float* rstd; int64_t ssb, sst;
+    const float* gamma; const float* beta;
+    const float* w;                   /* [C][P] */
+    const float* bias;                /* [C] or NULL */
+    float* y; int64_t ldy, ybs;
+    const float* alpha_out;           /* statistics of prelu(y, alpha_out); NULL: no statistics */
+    double* esums;                    /* [batch][2] += */
+    float* ecol; int64_t ecol_ld;     /* [batch][2][ecol_ld] += */
+} ctn_dw_fwd_args;
+
+int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream);
+
+/* Backward of the above plus both neighbouring norm/PReLU backward pieces:
+ *   dy2 = (gamma2*dn2*rstd2 + c1 + (prelu(y2)-mean2)*c2) * (y2 > 0 ? 1 : alpha2)   [if oflags has NORMBWD,
+ *          else dy2 = dn2]
+ *   dn1[t] = sum_k w[k] * dy2[t - k*dilation + pad_left]            -> dx
+ *   dw[c][k] += sum_t dy2[t] * n1[t + k*dilation - pad_left],  dbias[c] += sum_t dy2[t]
+ *   dgamma2[c] += sum dn2*xhat2, dbeta2[c] += sum dn2, dalpha2 += sum du2*min(y2,0)
+ *   norm-1 backward sums of g1 = gamma1*dn1 and g1*xhat1 (isums / icol), dgamma1, dbeta1.
+ * (autograd of src/models/tdcn.py:119-132,181-187) */
+typedef struct {
+    int32_t batch, C, T, P;
+    int32_t dilation, pad_left;
+    int32_t xflags;                   /* input-side transform used in forward */
+    int32_t oflags;                   /* 0 or CTN_XF_NORMBWD for the output side */
+    int32_t cln; int32_t pad0;
+    /* output side */
+    const float* dn2; int64_t lddn2, dn2bs;
+    const float* y2;  int64_t ldy2,  y2bs;
+    const float* alpha2;
+    const float* mean2; const float* rstd2; const float* c1_2; const float* c2_2; int64_t ssb2, sst2;
+    const float* gamma2;
+    float* dgamma2; float* dbeta2; double* dalpha2;
+    /* input side */
+    const float* x; int64_t ldx, xbs;
+    const float* alpha1;
+    const float* mean1; const float* rstd1; int64_t ssb1, sst1;
+    const float* gamma1; const float* beta1;
+    const float* w;
+    float* dw; float* dbias;          /* [C][P] +=, [C] += (dbias may be NULL) */
+    float* dx; int64_t lddx, dxbs;    /* dn1 */
+    double* isums; float* icol; int64_t icol_ld;   /* norm-1 backward sums (+=) */
+    float* dgamma1; float* dbeta1;
+} ctn_dw_bwd_args;
+
+int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder / decoder (src/models/filterbank.py:205-251)
+ * ------------------------------------------------------------------------------------------- */
+/* w[b][n][t] = act(sum_l W[n][l] * xp[b][t*S + l]),  xp[tau] = x[b][tau - pad_left] inside [0, Tin) else 0:
+ * the F.pad of conv_tasnet.py:149 and nn.Conv1d(1, N, L, stride=S, bias=False) + optional ReLU of
+ * filterbank.py:212-230.  x is (batch, Tin) with row stride xbs; L <= 64.  Optionally accumulates the
+ * statistics of the separator's entry norm (conv_tasnet.py:370): sums (gLN) or col (cLN), else both NULL. */
+int ctn_encoder_fwd(const float* x, int64_t xbs, int Tin, int pad_left, int batch, const float* W, int N, int L,
+                    int S, int relu, float* w, int Tf, int64_t ldw, double* sums, float* col, int64_t col_ld,
+                    void* stream);
+
+/* xhat[b][s][tau - trim_left] = sum_n sum_{t*S+l = tau} Wd[n][l] * w[b][n][t] * mask[b][s*N+n][t]
+ * for 0 <= tau - trim_left < Tout: the mask product of conv_tasnet.py:159-160, nn.ConvTranspose1d(N, 1, L,
+ * stride=S, bias=False) of filterbank.py:243-247 and the trim of conv_tasnet.py:169.  mask may be NULL
+ * (plain transposed convolution of w, n_src = 1).  L <= 32. */
+int ctn_maskdecode_fwd(const float* w, int64_t ldw, const float* mask, int64_t ldm, int batch, int n_src,
+                       int N, int Tf, const float* Wd, int L, int S, float* out, int64_t out_ss,
+                       int64_t out_bs, int Tout, int trim_left, void* stream);
+
+/* Backward of ctn_maskdecode_fwd with a sigmoid mask:
+ *   dwh = sum_l Wd[n][l]*dout[b][s][t*S+l-trim_left];  dz = dwh*w*m*(1-m) (sigmoid_bwd=1) or dwh*w;
+ *   dw_dec[b][n][t] = sum_s dwh*m;   dWd[n][l] += sum w*m*dout.   L <= 16, n_src <= 3.
+ * dz may be NULL when mask is NULL. */
+int ctn_maskdecode_bwd(const float* dout, int64_t dout_ss, int64_t dout_bs, int Tout, int trim_left,
+                       const float* w, int64_t ldw, const float* mask, int64_t ldm, int batch, int n_src,
+                       int N, int Tf, const float* Wd, int L, int S, int sigmoid_bwd, float* dz, int64_t lddz,
+                       float* dw_dec, int64_t lddw, float* dWd, void* stream);
+
+/* Encoder backward: dwt = [relu ? (w > 0) : 1] * (dw_a + norm_bwd(dn, w)) ; dW[n][l] += sum_t dwt*xp[t*S+l];
+ * dgamma[n] += sum dn*xhat ; dbeta[n] += sum dn.  dw_a may be NULL; dn and the norm arguments may be NULL
+ * (no entry norm).  dwt_out (batch, N, lddwt), if not NULL, receives dwt (the gradient w.r.t. the
+ * encoder's pre-activation output).  L <= 16. */
+int ctn_encoder_bwd(const float* x, int64_t xbs, int Tin, int pad_left, int batch, int N, int L, int S, int relu,
+                    const float* w, int Tf, int64_t ldw, const float* dw_a, int64_t lddwa, const float* dn,
+                    int64_t lddn, const float* mean, const float* rstd, const float* c1, const float* c2,
+                    int64_t ssb, int64_t sst, const float* gamma, float* dW, float* dgamma, float* dbeta,
+                    float* dwt_out, int64_t lddwt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Utterance-level PIT SI-SDR (src/criterion/pit.py:9-44 over src/criterion/sdr.py:122-139,198-227)
+ * ------------------------------------------------------------------------------------------- */
+/* work: double[batch * (2*S*S + S)] zeroed by the caller.  pair[b][i][j] = SI-SDR(est_i, tgt_j) in dB.
+ * loss_b[b] = min over permutations p (itertools order, first minimum wins) of -mean_i pair[i][p(i)];
+ * perm[b][i] = p(i) (int64); coef[b][i][2] = (a, c) with d loss_b / d est_i = a*tgt_{p(i)} + c*est_i.
+ * fixed_perm != 0 skips the search and uses the identity assignment (plain NegSISDR, sdr.py:198-227).
+ * S <= 4. */
+int ctn_pit_sisdr_fwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
+                      float eps, int fixed_perm, double* work, float* pair, float* loss_b, int64_t* perm,
+                      float* coef, void* stream);
+/* dest[b][i][t] = gscale[b*gs_bstride + i*gs_istride] * (a*tgt[b][p(i)][t] + c*est[b][i][t]) */
+int ctn_pit_sisdr_bwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
+                      const int64_t* perm, const float* coef, const float* gscale, int gs_bstride, int gs_istride,
+                      float* dest, int64_t dss, int64_t dbs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step on flat fp32 buffers (egs/wsj0-mix/common/src/driver.py:152-155:
+ * clip_grad_norm_(max_norm) then torch.optim.Adam.step)
+ * ------------------------------------------------------------------------------------------- */
+/* acc[0] += sum g^2 */
+int ctn_sumsq(const float* g, int64_t n, double* acc, void* stream);
+/* clip = max_norm > 0 ? min(1, max_norm/(sqrt(sumsq[0]) + 1e-6)) : 1;  g' = clip * grad_scale * g;
+ * Adam: m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps) */
+int ctn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
+                  float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTN_H */

@@ -1,0 +1,74 @@
+// Internal helpers shared by the gfx950 kernels of libctn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ctn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void ctn_set_error(const char* fmt, ...);
+
+#define CTN_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            ctn_set_error(__VA_ARGS__);   \
+            return CTN_ERR_ARG;           \
+        }                                 \
+    } while (0)
+
+#define CTN_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            ctn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return CTN_ERR_LAUNCH;                                               \
+        }                                                                        \
+    } while (0)
+
+static inline bool ctn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int ctn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+#define CTN_WAVE 64
+
+__device__ __forceinline__ float ctn_prelu(float v, float a) { return v > 0.f ? v : a * v; }
+
+__device__ __forceinline__ float ctn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double ctn_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum NV per-thread values over the block.  After the call threads 0..NV-1 hold total i in their
+// return value (thread i -> v[i] summed); smem needs NV * (blockDim.x / 64) floats.
+template <int NV>
+__device__ __forceinline__ float ctn_block_sum(float (&v)[NV], float* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = ctn_wave_sum(v[i]);
+        if (lane == 0) smem[wave * NV + i] = s;
+    }
+    __syncthreads();
+    float tot = 0.f;
+    if ((int)threadIdx.x < NV) {
+        for (int w = 0; w < nw; ++w) tot += smem[w * NV + threadIdx.x];
+    }
+    __syncthreads();
+    return tot;
+}
+
+__device__ __forceinline__ f32x4 ctn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void ctn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Per-frame statistics of 4 consecutive frames starting at t (gLN: stride 0 -> one value).
+struct Stat4 {
+    float mean[4], rstd[4], c1[4], c2[4];
+};

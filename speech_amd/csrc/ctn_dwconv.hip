@@ -1,0 +1,341 @@
+// Fused dilated depthwise convolution kernels (forward and backward), gfx950.
+//
+// A block owns CG consecutive channels of one batch element and one time tile [t0, t0 + TT).  For the
+// common 4 s / 8 kHz workload (T = 3999 frames) a tile is the whole row, so no halo is ever re-read.
+// Per channel the block stages the transformed input row (tile + dilation halo) in LDS, synchronises,
+// and every thread then produces 4 consecutive output frames from LDS taps.  Input-side PReLU + layer
+// norm are applied while staging (zero padding is applied AFTER the norm, as F.pad does in
+// src/models/tdcn.py:132), statistics of the output-side PReLU are reduced on the way out, so each
+// activation crosses HBM exactly once in each direction.
+#include "ctn_common.h"
+
+namespace {
+
+constexpr int NTH = 256;
+constexpr int MAXP = 8;
+
+__device__ __forceinline__ int floor4(int v) { return v & ~3; }
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, const int CG, const int TT,
+                                                     const int lw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[2 * (NTH / 64)];
+    const int b = blockIdx.z, c0 = blockIdx.y * CG, t0 = blockIdx.x * TT;
+    const int T = a.T, P = a.P, d = a.dilation, padL = a.pad_left;
+    const int tA = floor4(t0 - padL);
+    const int tid = threadIdx.x;
+    const float ain = a.alpha_in ? a.alpha_in[0] : 1.f;
+    const float aout = a.alpha_out ? a.alpha_out[0] : 1.f;
+    const bool do_stats = a.alpha_out != nullptr || a.esums != nullptr || a.ecol != nullptr;
+    const int cend = min(c0 + CG, a.C);
+    const int t_end = min(t0 + TT, T);
+
+    float s1 = 0.f, s2 = 0.f;                 // gLN partial sums
+    float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};   // cLN per-frame sums (one float4 per thread)
+
+    for (int c = c0; c < cend; ++c) {
+        // ---- stage the transformed, zero-padded input row
+        const float* xrow = a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx;
+        const float g = (a.xflags & CTN_XF_NORM) ? a.gamma[c] : 1.f;
+        const float be = (a.xflags & CTN_XF_NORM) ? a.beta[c] : 0.f;
+        for (int i4 = tid; i4 < lw / 4; i4 += NTH) {
+            const int t = tA + 4 * i4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < T) {
+                v = ctn_ld4(xrow + t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u = v[e];
+                    if (a.xflags & CTN_XF_PRELU) u = ctn_prelu(u, ain);
+                    if (a.xflags & CTN_XF_NORM) {
+                        const int64_t si = (int64_t)b * a.ssb + (int64_t)min(t + e, T - 1) * a.sst;
+                        u = (u - a.mean[si]) * a.rstd[si] * g + be;
+                    }
+                    v[e] = (t + e < T) ? u : 0.f;
+                }
+            }
+            ctn_st4(&lds[4 * i4], v);
+        }
+        __syncthreads();
+        // ---- taps
+        float w[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) w[k] = (k < P) ? a.w[(int64_t)c * P + k] : 0.f;
+        const float bias = a.bias ? a.bias[c] : 0.f;
+        float* yrow = a.y + (int64_t)b * a.ybs + (int64_t)c * a.ldy;
+        for (int t = t0 + 4 * tid; t < t_end; t += 4 * NTH) {
+            const int base = t - padL - tA;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = bias;
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k)
+                    if (k < P) acc += w[k] * lds[base + e + k * d];
+                o[e] = acc;
+            }
+            ctn_st4(yrow + t, o);
+            if (do_stats) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = (t + e < T) ? ctn_prelu(o[e], aout) : 0.f;
+                    if (a.cln) {
+                        cs1[e] += u;
+                        cs2[e] += u * u;
+                    } else {
+                        s1 += u;
+                        s2 += u * u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!do_stats) return;
+    if (a.cln) {
+        const int t = t0 + 4 * tid;   // host guarantees TT <= 4 * NTH in cLN mode
+        if (t < t_end) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t + e < T) {
+                    atomicAdd(a.ecol + ((int64_t)b * 2 + 0) * a.ecol_ld + t + e, cs1[e]);
+                    atomicAdd(a.ecol + ((int64_t)b * 2 + 1) * a.ecol_ld + t + e, cs2[e]);
+                }
+        }
+    } else {
+        float v[2] = {s1, s2};
+        const float tot = ctn_block_sum<2>(v, red);
+        if (tid < 2) atomicAdd(a.esums + (int64_t)b * 2 + tid, (double)tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// LDS rows (same indexing, origin tA, halo H on both sides):
+//   D [i] = dy2[tA + i]   (gradient w.r.t. the conv output, after the output-side norm/PReLU backward)
+//   Xh[i] = xhat1[tA + i] (normalised input BEFORE gamma/beta, zero outside [0, T))
+// The conv input is n1 = gamma1 * xhat1 + beta1 inside [0, T) and 0 outside, hence
+//   dw[k] = gamma1 * sum D[t] * Xh[t + k d - padL] + beta1 * sum D[t] * [0 <= t + k d - padL < T].
+template <int P>
+__global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, const int CG, const int TT,
+                                                     const int lw, const int H) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NV = 5 + 2 * P;
+    __shared__ float red[(NV > 3 ? NV : 3) * (NTH / 64)];
+    float* D = lds;
+    float* Xh = lds + lw;
+    const int b = blockIdx.z, c0 = blockIdx.y * CG, t0 = blockIdx.x * TT;
+    const int T = a.T, d = a.dilation, padL = a.pad_left;
+    const int tA = floor4(t0 - H);
+    const int tid = threadIdx.x;
+    const float a1 = a.alpha1 ? a.alpha1[0] : 1.f;
+    const float a2 = a.alpha2 ? a.alpha2[0] : 1.f;
+    const bool obwd = (a.oflags & CTN_XF_NORMBWD) != 0;
+    const bool inorm = (a.xflags & CTN_XF_NORM) != 0;
+    const int cend = min(c0 + CG, a.C);
+    const int t_end = min(t0 + TT, T);
+
+    float dalpha2 = 0.f, s1 = 0.f, s2 = 0.f;
+    float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
+
+    for (int c = c0; c < cend; ++c) {
+        const float* dnrow = a.dn2 + (int64_t)b * a.dn2bs + (int64_t)c * a.lddn2;
+        const float* y2row = obwd ? a.y2 + (int64_t)b * a.y2bs + (int64_t)c * a.ldy2 : nullptr;
+        const float* xrow = a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx;
+        const float g2 = obwd ? a.gamma2[c] : 1.f;
+        float dgamma2 = 0.f, dbeta2 = 0.f, dbias = 0.f;
+        // ---- stage D and Xh
+        for (int i4 = tid; i4 < lw / 4; i4 += NTH) {
+            const int t = tA + 4 * i4;
+            f32x4 dv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < T) {
+                const f32x4 dn = ctn_ld4(dnrow + t);
+                const f32x4 x = ctn_ld4(xrow + t);
+                f32x4 y2 = {0.f, 0.f, 0.f, 0.f};
+                if (obwd) y2 = ctn_ld4(y2row + t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool valid = t + e < T;
+                    const bool interior = valid && t + e >= t0 && t + e < t_end;
+                    float dy = dn[e];
+                    if (obwd) {
+                        const int64_t si = (int64_t)b * a.ssb2 + (int64_t)min(t + e, T - 1) * a.sst2;
+                        const float mean = a.mean2[si], rstd = a.rstd2[si];
+                        const float u = ctn_prelu(y2[e], a2);
+                        const float xc = u - mean;
+                        const float du = g2 * dn[e] * rstd + a.c1_2[si] + xc * a.c2_2[si];
+                        dy = y2[e] > 0.f ? du : a2 * du;
+                        if (interior) {
+                            dgamma2 += dn[e] * xc * rstd;
+                            dbeta2 += dn[e];
+                            if (!(y2[e] > 0.f)) dalpha2 += du * y2[e];
+                        }
+                    }
+                    if (interior) dbias += dy;
+                    dv[e] = valid ? dy : 0.f;
+                    float u1 = x[e];
+                    if (a.xflags & CTN_XF_PRELU) u1 = ctn_prelu(u1, a1);
+                    if (inorm) {
+                        const int64_t si = (int64_t)b * a.ssb1 + (int64_t)min(t + e, T - 1) * a.sst1;
+                        u1 = (u1 - a.mean1[si]) * a.rstd1[si];
+                    }
+                    xv[e] = valid ? u1 : 0.f;
+                }
+            }
+            ctn_st4(&D[4 * i4], dv);
+            ctn_st4(&Xh[4 * i4], xv);
+        }
+        __syncthreads();
+        // ---- input gradient, weight gradient, norm-1 reductions
+        float w[P], dwa[P], dwb[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            w[k] = a.w[(int64_t)c * P + k];
+            dwa[k] = 0.f;
+            dwb[k] = 0.f;
+        }
+        const float g1 = inorm ? a.gamma1[c] : 1.f;
+        float dgamma1 = 0.f, dbeta1 = 0.f;
+        float* dxrow = a.dx + (int64_t)b * a.dxbs + (int64_t)c * a.lddx;
+        for (int t = t0 + 4 * tid; t < t_end; t += 4 * NTH) {
+            const int i0 = t - tA;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+                const float dy = D[i0 + e];
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    acc += w[k] * D[i0 + e - k * d + padL];
+                    const int ti = t + e + k * d - padL;
+                    dwa[k] += dy * Xh[i0 + e + k * d - padL];
+                    dwb[k] += (ti >= 0 && ti < T) ? dy : 0.f;
+                }
+                o[e] = acc;
+                if (t + e < T) {
+                    const float xh = Xh[i0 + e];
+                    const float g = g1 * acc;
+                    dgamma1 += acc * xh;
+                    dbeta1 += acc;
+                    if (a.cln) {
+                        cs1[e] += g;
+                        cs2[e] += g * xh;
+                    } else {
+                        s1 += g;
+                        s2 += g * xh;
+                    }
+                }
+            }
+            ctn_st4(dxrow + t, o);
+        }
+        // ---- per-channel reductions
+        float v[NV];
+        v[0] = dgamma2; v[1] = dbeta2; v[2] = dbias; v[3] = dgamma1; v[4] = dbeta1;
+        const float be1 = inorm ? a.beta1[c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            v[5 + k] = g1 * dwa[k] + be1 * dwb[k];
+            v[5 + P + k] = 0.f;
+        }
+        const float tot = ctn_block_sum<NV>(v, red);   // also the barrier before LDS is overwritten
+        if (tid == 0 && obwd && a.dgamma2) atomicAdd(a.dgamma2 + c, tot);
+        if (tid == 1 && obwd && a.dbeta2) atomicAdd(a.dbeta2 + c, tot);
+        if (tid == 2 && a.dbias) atomicAdd(a.dbias + c, tot);
+        if (tid == 3 && inorm && a.dgamma1) atomicAdd(a.dgamma1 + c, tot);
+        if (tid == 4 && inorm && a.dbeta1) atomicAdd(a.dbeta1 + c, tot);
+        if (tid >= 5 && tid < 5 + P) atomicAdd(a.dw + (int64_t)c * P + (tid - 5), tot);
+    }
+    // ---- per-sample reductions
+    {
+        float v[3] = {dalpha2, s1, s2};
+        const float tot = ctn_block_sum<3>(v, red);
+        if (tid == 0 && obwd && a.dalpha2) atomicAdd(a.dalpha2, (double)tot);
+        if (!a.cln && a.isums && (tid == 1 || tid == 2)) atomicAdd(a.isums + (int64_t)b * 2 + (tid - 1), (double)tot);
+    }
+    if (a.cln && a.icol) {
+        const int t = t0 + 4 * tid;
+        if (t < t_end) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t + e < T) {
+                    atomicAdd(a.icol + ((int64_t)b * 2 + 0) * a.icol_ld + t + e, cs1[e]);
+                    atomicAdd(a.icol + ((int64_t)b * 2 + 1) * a.icol_ld + t + e, cs2[e]);
+                }
+        }
+    }
+}
+
+bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
+    return p && ctn_aligned16(p) && ld % 4 == 0 && bs % 4 == 0 && ld >= T;
+}
+
+// Tile choice: whole rows when they fit (no halo re-reads); cLN needs <= 1 float4 per thread per channel.
+void pick_tile(int T, int halo2, bool cln, int lds_rows, int* CG, int* TT, int* lw) {
+    const int max_floats = (cln ? 48 : 40) * 1024 / 4 / lds_rows;
+    int tt = (T + 3) & ~3;
+    if (cln) tt = tt < 4 * NTH ? tt : 4 * NTH;
+    while (tt + halo2 + 3 > max_floats && tt > 256) tt = ((tt / 2) + 3) & ~3;
+    *TT = tt;
+    *lw = (tt + halo2 + 3 + 3) & ~3;
+    *CG = cln ? 8 : 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream) {
+    CTN_REQUIRE(args, "ctn_dw_fwd: null args");
+    const ctn_dw_fwd_args& a = *args;
+    CTN_REQUIRE(a.batch > 0 && a.C > 0 && a.T > 0 && a.P >= 1 && a.P <= MAXP && a.dilation >= 1,
+                "ctn_dw_fwd: bad shape (P <= %d)", MAXP);
+    CTN_REQUIRE(a.pad_left >= 0 && a.pad_left <= (a.P - 1) * a.dilation, "ctn_dw_fwd: pad_left out of range");
+    CTN_REQUIRE(act_ok(a.x, a.ldx, a.xbs, a.T) && act_ok(a.y, a.ldy, a.ybs, a.T) && a.w, "ctn_dw_fwd: x / y layout");
+    if (a.xflags & CTN_XF_NORM)
+        CTN_REQUIRE(a.mean && a.rstd && a.gamma && a.beta, "ctn_dw_fwd: NORM needs mean, rstd, gamma, beta");
+    const bool stats = a.alpha_out || a.esums || a.ecol;
+    if (stats) CTN_REQUIRE(a.cln ? (a.ecol && a.ecol_ld >= a.T) : (a.esums != nullptr), "ctn_dw_fwd: statistics buffer");
+    int CG, TT, lw;
+    pick_tile(a.T, (a.P - 1) * a.dilation, a.cln != 0, 1, &CG, &TT, &lw);
+    CTN_REQUIRE((size_t)lw * 4 <= 64 * 1024, "ctn_dw_fwd: dilation halo too large for LDS");
+    dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
+    hipLaunchKernelGGL(dw_fwd_kernel, grid, dim3(NTH), (size_t)lw * 4, (hipStream_t)stream, a, CG, TT, lw);
+    CTN_CHECK_LAUNCH("ctn_dw_fwd");
+    return CTN_OK;
+}
+
+int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
+    CTN_REQUIRE(args, "ctn_dw_bwd: null args");
+    const ctn_dw_bwd_args& a = *args;
+    CTN_REQUIRE(a.batch > 0 && a.C > 0 && a.T > 0 && a.P >= 1 && a.P <= MAXP && a.dilation >= 1,
+                "ctn_dw_bwd: bad shape (P <= %d)", MAXP);
+    CTN_REQUIRE(a.pad_left >= 0 && a.pad_left <= (a.P - 1) * a.dilation, "ctn_dw_bwd: pad_left out of range");
+    CTN_REQUIRE(act_ok(a.dn2, a.lddn2, a.dn2bs, a.T) && act_ok(a.x, a.ldx, a.xbs, a.T) &&
+                    act_ok(a.dx, a.lddx, a.dxbs, a.T) && a.w && a.dw,
+                "ctn_dw_bwd: dn2 / x / dx layout");
+    if (a.oflags & CTN_XF_NORMBWD)
+        CTN_REQUIRE(act_ok(a.y2, a.ldy2, a.y2bs, a.T) && a.mean2 && a.rstd2 && a.c1_2 && a.c2_2 && a.gamma2,
+                    "ctn_dw_bwd: output-side NORMBWD needs y2, stats, gamma2");
+    if (a.xflags & CTN_XF_NORM)
+        CTN_REQUIRE(a.mean1 && a.rstd1 && a.gamma1 && a.beta1, "ctn_dw_bwd: input-side NORM needs stats, gamma1, beta1");
+    if (a.cln) CTN_REQUIRE(!a.icol || a.icol_ld >= a.T, "ctn_dw_bwd: icol_ld < T");
+    const int padR = (a.P - 1) * a.dilation - a.pad_left;
+    const int H = a.pad_left > padR ? a.pad_left : padR;
+    int CG, TT, lw;
+    pick_tile(a.T, 2 * H, a.cln != 0, 2, &CG, &TT, &lw);
+    CTN_REQUIRE((size_t)lw * 8 <= 64 * 1024, "ctn_dw_bwd: dilation halo too large for LDS");
+    dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
+    const size_t shmem = (size_t)lw * 8;
+    hipStream_t s = (hipStream_t)stream;
+#define CTN_DW_BWD_CASE(PP) \
+    case PP: hipLaunchKernelGGL(dw_bwd_kernel<PP>, grid, dim3(NTH), shmem, s, a, CG, TT, lw, H); break;
+    switch (a.P) {
+        CTN_DW_BWD_CASE(1) CTN_DW_BWD_CASE(2) CTN_DW_BWD_CASE(3) CTN_DW_BWD_CASE(4)
+        CTN_DW_BWD_CASE(5) CTN_DW_BWD_CASE(6) CTN_DW_BWD_CASE(7) CTN_DW_BWD_CASE(8)
+    }
+#undef CTN_DW_BWD_CASE
+    CTN_CHECK_LAUNCH("ctn_dw_bwd");
+    return CTN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// Utterance-level PIT SI-SDR (forward search + backward of the winning permutation) and the flat
+// clip + Adam optimizer step, gfx950.
+//
+// SI-SDR(e, t) = 10 log10( (|a t|^2 + eps) / (|a t - e|^2 + eps) ),  a = <e,t> / (|t|^2 + eps)
+// (src/criterion/sdr.py:135-137).  The S x S matrix of pairwise values is built in two passes over the
+// signals: pass 1 the dot products <e_i, t_j> and |t_j|^2, pass 2 the residual energies |a_ij t_j - e_i|^2
+// formed explicitly (the algebraic shortcut cancels catastrophically at high SDR).  Per-thread partial
+// sums are fp32 over a few dozen samples, everything above that is accumulated in fp64, so the S! candidate
+// losses are accurate to fp32 rounding and the arg-min reproduces the reference's choice, with exact ties
+// (bit-identical candidates) resolved to the first permutation like torch.min.
+#include "ctn_common.h"
+
+namespace {
+
+constexpr int NTH = 256;
+constexpr int CHUNK = 4096;   // samples per block
+
+// work layout per batch element: dot[S*S] | tt[S] | res[S*S]
+template <int S>
+__global__ __launch_bounds__(NTH) void pit_pass1_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                        int T, int64_t ss, int64_t bs, double* work) {
+    __shared__ float red[(S * S + S) * (NTH / 64)];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * CHUNK, t1 = min(t0 + CHUNK, T);
+    float v[S * S + S];
+#pragma unroll
+    for (int i = 0; i < S * S + S; ++i) v[i] = 0.f;
+    for (int t = t0 + threadIdx.x; t < t1; t += NTH) {
+        float e[S], g[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            e[i] = est[(int64_t)b * bs + (int64_t)i * ss + t];
+            g[i] = tgt[(int64_t)b * bs + (int64_t)i * ss + t];
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) v[i * S + j] += e[i] * g[j];
+            v[S * S + i] += g[i] * g[i];
+        }
+    }
+    const float tot = ctn_block_sum<S * S + S>(v, red);
+    if (threadIdx.x < S * S + S) atomicAdd(work + (int64_t)b * (2 * S * S + S) + threadIdx.x, (double)tot);
+}
+
+template <int S>
+__global__ __launch_bounds__(NTH) void pit_pass2_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                        int T, int64_t ss, int64_t bs, float eps, double* work) {
+    __shared__ float red[(S * S) * (NTH / 64)];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * CHUNK, t1 = min(t0 + CHUNK, T);
+    double* wb = work + (int64_t)b * (2 * S * S + S);
+    float alpha[S * S];
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) alpha[i * S + j] = (float)wb[i * S + j] / ((float)wb[S * S + j] + eps);
+    float v[S * S];
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) v[i] = 0.f;
+    for (int t = t0 + threadIdx.x; t < t1; t += NTH) {
+        float e[S], g[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            e[i] = est[(int64_t)b * bs + (int64_t)i * ss + t];
+            g[i] = tgt[(int64_t)b * bs + (int64_t)i * ss + t];
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const float r = alpha[i * S + j] * g[j] - e[i];
+                v[i * S + j] += r * r;
+            }
+    }
+    const float tot = ctn_block_sum<S * S>(v, red);
+    if (threadIdx.x < S * S) atomicAdd(wb + S * S + S + threadIdx.x, (double)tot);
+}
+
+template <int S>
+__global__ void pit_finalize_kernel(const double* __restrict__ work, int batch, float eps, int fixed_perm,
+                                    float* pair, float* loss_b, int64_t* perm, float* coef) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double* wb = work + (int64_t)b * (2 * S * S + S);
+    float pr[S * S];
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            const float dot = (float)wb[i * S + j], tt = (float)wb[S * S + j], res = (float)wb[S * S + S + i * S + j];
+            const float alpha = dot / (tt + eps);
+            const float num = alpha * alpha * tt + eps;
+            const float den = res + eps;
+            const float v = 10.f * log10f(num / den);
+            pr[i * S + j] = v;
+            pair[(int64_t)b * S * S + i * S + j] = v;
+        }
+    // permutations in itertools (lexicographic) order; keep the first minimum
+    int p[S], best[S];
+    for (int i = 0; i < S; ++i) p[i] = i;
+    float best_loss = 0.f;
+    bool first = true;
+    while (true) {
+        float acc = 0.f;
+        for (int i = 0; i < S; ++i) acc += -pr[i * S + p[i]];
+        const float l = acc / (float)S;
+        if (first || l < best_loss) {
+            best_loss = l;
+            for (int i = 0; i < S; ++i) best[i] = p[i];
+            first = false;
+        }
+        if (fixed_perm) break;
+        // next lexicographic permutation
+        int k = S - 2;
+        while (k >= 0 && p[k] > p[k + 1]) --k;
+        if (k < 0) break;
+        int l2 = S - 1;
+        while (p[l2] < p[k]) --l2;
+        int tmp = p[k]; p[k] = p[l2]; p[l2] = tmp;
+        for (int lo = k + 1, hi = S - 1; lo < hi; ++lo, --hi) {
+            tmp = p[lo]; p[lo] = p[hi]; p[hi] = tmp;
+        }
+    }
+    loss_b[b] = best_loss;
+    // gradient coefficients of the winning assignment (fp64):
+    //   d sisdr / d e = K [ 2 a tt / ((tt+eps) num) - 2 rt / ((tt+eps) den) + 2 a / den ] t  -  K (2/den) e
+    //   with K = 10/ln 10, rt = <a t - e, t> = -dot * eps / (tt + eps)
+    const double K = 10.0 / log(10.0);
+    for (int i = 0; i < S; ++i) {
+        const int j = best[i];
+        perm[(int64_t)b * S + i] = j;
+        const double dot = wb[i * S + j], tt = wb[S * S + j], res = wb[S * S + S + i * S + j];
+        const double a = dot / (tt + (double)eps);
+        const double num = a * a * tt + (double)eps, den = res + (double)eps;
+        const double rt = -dot * (double)eps / (tt + (double)eps);
+        const double ct = K * (2.0 * a * tt / ((tt + eps) * num) - 2.0 * rt / ((tt + eps) * den) + 2.0 * a / den);
+        const double ce = -K * 2.0 / den;
+        coef[((int64_t)b * S + i) * 2 + 0] = (float)(-ct / (double)S);
+        coef[((int64_t)b * S + i) * 2 + 1] = (float)(-ce / (double)S);
+    }
+}
+
+__global__ __launch_bounds__(NTH) void pit_bwd_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                      int S, int T, int64_t ss, int64_t bs,
+                                                      const int64_t* __restrict__ perm, const float* __restrict__ coef,
+                                                      const float* __restrict__ gscale, int gs_bstride,
+                                                      int gs_istride, float* dest, int64_t dss, int64_t dbs) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int t = blockIdx.x * NTH + threadIdx.x;
+    if (t >= T) return;
+    const int j = (int)perm[(int64_t)b * S + i];
+    const float g = gscale[(int64_t)b * gs_bstride + (int64_t)i * gs_istride];
+    const float a = coef[((int64_t)b * S + i) * 2 + 0] * g, c = coef[((int64_t)b * S + i) * 2 + 1] * g;
+    dest[(int64_t)b * dbs + (int64_t)i * dss + t] =
+        a * tgt[(int64_t)b * bs + (int64_t)j * ss + t] + c * est[(int64_t)b * bs + (int64_t)i * ss + t];
+}
+
+// ------------------------------------------------------------------------------------------ optimizer
+__global__ __launch_bounds__(NTH) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* acc) {
+    __shared__ float red[NTH / 64];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NTH + threadIdx.x; i < n; i += (int64_t)gridDim.x * NTH) s += g[i] * g[i];
+    float v[1] = {s};
+    const float tot = ctn_block_sum<1>(v, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)tot);
+}
+
+__global__ __launch_bounds__(NTH) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const double* sumsq, float max_norm, float grad_scale, float lr,
+                                                   float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    float clip = grad_scale;
+    if (max_norm > 0.f && sumsq) {
+        const float norm = (float)sqrt(sumsq[0]) * fabsf(grad_scale);
+        const float c = max_norm / (norm + 1e-6f);
+        clip *= fminf(c, 1.f);
+    }
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * NTH + threadIdx.x; i < n; i += (int64_t)gridDim.x * NTH) {
+        const float gi = g[i] * clip;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctn_pit_sisdr_fwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs, float eps,
+                      int fixed_perm, double* work, float* pair, float* loss_b, int64_t* perm, float* coef,
+                      void* stream) {
+    CTN_REQUIRE(est && tgt && work && pair && loss_b && perm && coef, "ctn_pit_sisdr_fwd: null pointer");
+    CTN_REQUIRE(batch > 0 && T > 0 && S >= 1 && S <= 4, "ctn_pit_sisdr_fwd: supports 1..4 sources");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ctn_cdiv(T, CHUNK), batch);
+#define CTN_PIT_CASE(SS)                                                                                        \
+    case SS:                                                                                                    \
+        hipLaunchKernelGGL(pit_pass1_kernel<SS>, grid, dim3(NTH), 0, s, est, tgt, T, ss, bs, work);             \
+        hipLaunchKernelGGL(pit_pass2_kernel<SS>, grid, dim3(NTH), 0, s, est, tgt, T, ss, bs, eps, work);        \
+        hipLaunchKernelGGL(pit_finalize_kernel<SS>, dim3(ctn_cdiv(batch, 64)), dim3(64), 0, s, work, batch, eps, \
+                           fixed_perm, pair, loss_b, perm, coef);                                                           \
+        break;
+    switch (S) { CTN_PIT_CASE(1) CTN_PIT_CASE(2) CTN_PIT_CASE(3) CTN_PIT_CASE(4) }
+#undef CTN_PIT_CASE
+    CTN_CHECK_LAUNCH("ctn_pit_sisdr_fwd");
+    return CTN_OK;
+}
+
+int ctn_pit_sisdr_bwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
+                      const int64_t* perm, const float* coef, const float* gscale, int gs_bstride, int gs_istride,
+                      float* dest, int64_t dss, int64_t dbs, void* stream) {
+    CTN_REQUIRE(est && tgt && perm && coef && gscale && dest && batch > 0 && S >= 1 && T > 0,
+                "ctn_pit_sisdr_bwd: bad arguments");
+    dim3 grid(ctn_cdiv(T, NTH), S, batch);
+    hipLaunchKernelGGL(pit_bwd_kernel, grid, dim3(NTH), 0, (hipStream_t)stream, est, tgt, S, T, ss, bs, perm, coef,
+                       gscale, gs_bstride, gs_istride, dest, dss, dbs);
+    CTN_CHECK_LAUNCH("ctn_pit_sisdr_bwd");
+    return CTN_OK;
+}
+
+int ctn_sumsq(const float* g, int64_t n, double* acc, void* stream) {
+    CTN_REQUIRE(g && acc && n > 0, "ctn_sumsq: bad arguments");
+    int64_t blocks = (n + NTH * 8 - 1) / (NTH * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(NTH), 0, (hipStream_t)stream, g, n, acc);
+    CTN_CHECK_LAUNCH("ctn_sumsq");
+    return CTN_OK;
+}
+
+int ctn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm,
+                  float grad_scale, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+    CTN_REQUIRE(p && g && m && v && n > 0 && step >= 1, "ctn_adam_step: bad arguments");
+    CTN_REQUIRE(!(max_norm > 0.f) || sumsq, "ctn_adam_step: clipping needs sumsq");
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    int64_t blocks = (n + NTH * 4 - 1) / (NTH * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(NTH), 0, (hipStream_t)stream, p, g, m, v, n, sumsq,
+                       max_norm, grad_scale, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    CTN_CHECK_LAUNCH("ctn_adam_step");
+    return CTN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,529 @@
+"""Forward/backward schedules of the Conv-TasNet hot path over the HIP kernels, and the
+torch.autograd.Function wrappers the nn.Modules call.
+
+Each schedule is a fixed sequence of C-ABI launches (see include/ctn.h); PyTorch only supplies
+device memory, the current stream and the autograd graph edges.  Data flow of one residual layer
+(reference: src/models/tdcn.py:107-147 with :177-196 inlined), B = bottleneck, H = hidden channels:
+
+  forward   x (B) --gemm_nn[STATS]--> y1 (H, pre-PReLU) --dw_fwd[PReLU+norm on load, stats out]--> y2 (H)
+            --gemm_nn[PReLU+norm on load, HEADS]--> out = . + x (B),  skip_sum += . (Sc)
+  backward  (dout, dskip) --gemm_nn[NORMBWD epilogue]--> dn2 ; gemm_nt -> dWo, dWs, dbo, dbs
+            dn2 --dw_bwd--> dn1 (+ dwd, dbd, dgamma/dbeta 1 and 2, dalpha2)
+            dn1 --gemm_nn[NORMBWD on load, ADD dout]--> dx ; gemm_nt[NORMBWD on load] -> dW1, db1, dalpha1
+
+Only y1, y2 and the per-norm statistics are kept for backward; normalised tensors never exist in HBM.
+"""
+import torch
+
+from . import ops
+from .ops import (XF_PRELU, XF_NORM, XF_NORMBWD, EPI_STORE, EPI_STATS, EPI_HEADS, EPI_SIGMOID, EPI_PRELUBWD,
+                  EPI_NORMBWD, EPI_ADD, Accum, new_act, as_act)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+class GradSink:
+    """Zeroed gradient buffers for a list of parameters (one flat allocation, views per parameter).
+
+    PReLU slopes are reduced in fp64 by the kernels; their slots live in `dalpha` and are folded
+    into the fp32 views by finish()."""
+
+    def __init__(self, params, flat=None):
+        self.params = list(params)
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        if flat is None:
+            self.flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        else:                                  # caller-owned buffer (e.g. the trainer's all-reduce bucket)
+            assert flat.numel() == sum(sizes) and flat.dtype == torch.float32 and flat.is_contiguous()
+            self.flat = flat
+            self.flat.zero_()
+        self.views, self.offsets, off = [], [], 0
+        for p, n in zip(self.params, sizes):
+            self.views.append(self.flat[off:off + n].view(p.shape))
+            self.offsets.append(off)
+            off += n
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._alpha = []
+        self.dalpha = None
+
+    def g(self, p):
+        return None if p is None else self.views[self._index[id(p)]]
+
+    def alpha_slot(self, p):
+        """fp64 accumulator (1-element view) for PReLU slope p."""
+        if self.dalpha is None:
+            self.dalpha = torch.zeros(len(self.params), device=self.flat.device, dtype=torch.float64)
+        i = self._index[id(p)]
+        self._alpha.append(i)
+        return self.dalpha[i:i + 1]
+
+    def finish(self):
+        if self._alpha:
+            idx = sorted(set(self._alpha))
+            dev = self.flat.device
+            src = torch.tensor(idx, device=dev, dtype=torch.long)
+            dst = torch.tensor([self.offsets[i] for i in idx], device=dev, dtype=torch.long)
+            self.flat.index_copy_(0, dst, self.dalpha.index_select(0, src).float())
+        return self.views
+
+
+def _flat(p):
+    return None if p is None else p.detach().reshape(-1)
+
+
+class Layer:
+    """Detached, flattened parameter views of one ResidualBlock1d (+ its tdcn DepthwiseSeparableConv1d)."""
+
+    NAMES_DUAL = ["W1", "b1", "a1", "g1", "be1", "wd", "bd", "a2", "g2", "be2", "Wo", "bo", "Ws", "bs"]
+    NAMES_SINGLE = ["W1", "b1", "a1", "g1", "be1", "wd", "bd", "a2", "g2", "be2", "Ws", "bs"]
+
+    def __init__(self, tensors, dual):
+        names = self.NAMES_DUAL if dual else self.NAMES_SINGLE
+        assert len(tensors) == len(names)
+        self.dual = dual
+        self.orig = dict(zip(names, tensors))
+        for n in self.NAMES_DUAL:
+            setattr(self, n, None)
+        for n, t in zip(names, tensors):
+            setattr(self, n, t.detach())
+        self.H, self.Bc = self.W1.shape[0], self.W1.shape[1]
+        self.Sc = self.Ws.shape[0]
+        self.P = self.wd.shape[-1]
+
+
+def _pads(P, dilation, causal):
+    padding = (P - 1) * dilation                      # src/models/tdcn.py:123 with stride 1
+    return padding if causal else padding // 2        # :125-130
+
+
+# ------------------------------------------------------------------------------------------------ residual layer
+def layer_forward(L, x, skip, accumulate, dilation, causal, eps):
+    """x act (B, Bc, T); skip act (B, Sc, T) written (accumulate=False) or added to.  Returns out, saved."""
+    B, _, T = x.shape
+    dev = x.device
+    H, Bc, Sc, P = L.H, L.Bc, L.Sc, L.P
+    # bottleneck 1x1 + PReLU statistics
+    W1t = torch.empty((Bc, H), device=dev, dtype=torch.float32)
+    ops.transpose(L.W1.view(H, Bc), W1t, H)
+    y1 = new_act(B, H, T, dev)
+    acc1 = Accum(B, T, causal, dev)
+    ops.gemm_nn(H, T, Bc, B, W1t, H, x, y1, bias=L.b1, emode=EPI_STATS, ealpha=L.a1, eacc=acc1)
+    st1 = ops.finalize_stats(acc1, B, H, T, eps, dev)
+    # depthwise
+    y2 = new_act(B, H, T, dev)
+    acc2 = Accum(B, T, causal, dev)
+    ops.dw_fwd(y1, L.wd.view(H, P), L.bd, y2, dilation, _pads(P, dilation, causal), xflags=XF_PRELU | XF_NORM,
+               alpha_in=L.a1, stat=st1, gamma=L.g1.view(-1), beta=L.be1.view(-1), alpha_out=L.a2, acc=acc2)
+    st2 = ops.finalize_stats(acc2, B, H, T, eps, dev)
+    # heads
+    Mo = Bc if L.dual else 0
+    Mt = Mo + Sc
+    Wct = torch.empty((H, Mt), device=dev, dtype=torch.float32)
+    if L.dual:
+        ops.transpose(L.Wo.view(Bc, H), Wct, Mt, 0)
+    ops.transpose(L.Ws.view(Sc, H), Wct, Mt, Mo)
+    out = new_act(B, Bc, T, dev) if L.dual else None
+    ops.gemm_nn(Mt, T, H, B, Wct, Mt, y2, out if L.dual else skip, xflags=XF_PRELU | XF_NORM, alpha=L.a2, stat=st2,
+                gamma=L.g2.view(-1), beta=L.be2.view(-1), bias=L.bo, bias2=L.bs, emode=EPI_HEADS, Mo=Mo,
+                R=x if L.dual else None, Y2=skip, accumulate=accumulate)
+    return out, (x, y1, y2, st1, st2)
+
+
+def layer_backward(L, saved, dout, dskip, sink, dilation, causal, eps):
+    """dout act (B, Bc, T) or None; dskip act (B, Sc, T).  Accumulates parameter grads, returns dx."""
+    x, y1, y2, st1, st2 = saved
+    B, _, T = x.shape
+    dev = x.device
+    H, Bc, Sc, P = L.H, L.Bc, L.Sc, L.P
+    o = L.orig
+    dual = L.dual and dout is not None
+    # heads: input gradient with the norm-2 backward sums in the epilogue
+    dn2 = new_act(B, H, T, dev)
+    bacc2 = Accum(B, T, causal, dev)
+    if dual:
+        ops.gemm_nn(H, T, Bc + Sc, B, L.Wo.view(Bc, H), H, dout, dn2, A2=L.Ws.view(Sc, H), lda2=H, K1=Bc, Xb=dskip,
+                    emode=EPI_NORMBWD, E=y2, ealpha=L.a2, estat=st2, egamma=L.g2.view(-1), eacc=bacc2)
+        ops.gemm_nt(Bc + Sc, H, T, B, dout, y2, sink.g(o["Wo"]).view(Bc, H), H, Ab=dskip, M1=Bc,
+                    C2=sink.g(o["Ws"]).view(Sc, H), ldc2=H, a_rowsum=sink.g(o["bo"]), a_rowsum2=sink.g(o["bs"]),
+                    bflags=XF_PRELU | XF_NORM, b_alpha=L.a2, b_stat=st2, b_gamma=L.g2.view(-1), b_beta=L.be2.view(-1))
+    else:
+        ops.gemm_nn(H, T, Sc, B, L.Ws.view(Sc, H), H, dskip, dn2, emode=EPI_NORMBWD, E=y2, ealpha=L.a2, estat=st2,
+                    egamma=L.g2.view(-1), eacc=bacc2)
+        ops.gemm_nt(Sc, H, T, B, dskip, y2, sink.g(o["Ws"]).view(Sc, H), H, a_rowsum=sink.g(o["bs"]),
+                    bflags=XF_PRELU | XF_NORM, b_alpha=L.a2, b_stat=st2, b_gamma=L.g2.view(-1), b_beta=L.be2.view(-1))
+        if L.dual:   # the residual head exists but received no gradient
+            pass
+    ops.bwd_coefs(bacc2, st2, B, H, T, eps)
+    # depthwise backward (+ norm-2 / PReLU-2 backward on load, norm-1 sums on the way out)
+    dn1 = new_act(B, H, T, dev)
+    bacc1 = Accum(B, T, causal, dev)
+    ops.dw_bwd(dn2, y1, L.wd.view(H, P), sink.g(o["wd"]).view(H, P), sink.g(o["bd"]), dn1, dilation,
+               _pads(P, dilation, causal), xflags=XF_PRELU | XF_NORM, alpha1=L.a1, stat1=st1, gamma1=L.g1.view(-1),
+               beta1=L.be1.view(-1), dgamma1=sink.g(o["g1"]).view(-1), dbeta1=sink.g(o["be1"]).view(-1), iacc=bacc1,
+               y2=y2, alpha2=L.a2, stat2=st2, gamma2=L.g2.view(-1), dgamma2=sink.g(o["g2"]).view(-1),
+               dbeta2=sink.g(o["be2"]).view(-1), dalpha2=sink.alpha_slot(o["a2"]))
+    ops.bwd_coefs(bacc1, st1, B, H, T, eps)
+    # bottleneck: input gradient (+ residual path) and weight gradient, norm-1 / PReLU-1 backward on load
+    dx = new_act(B, Bc, T, dev)
+    ops.gemm_nn(Bc, T, H, B, L.W1.view(H, Bc), Bc, dn1, dx, xflags=XF_NORMBWD, X2=y1, alpha=L.a1, stat=st1,
+                gamma=L.g1.view(-1), emode=EPI_ADD, R=dout if dual else None)
+    ops.gemm_nt(H, Bc, T, B, dn1, x, sink.g(o["W1"]).view(H, Bc), Bc, aflags=XF_NORMBWD, A2=y1, a_alpha=L.a1,
+                a_stat=st1, a_gamma=L.g1.view(-1), a_rowsum=sink.g(o["b1"]), a_dalpha=sink.alpha_slot(o["a1"]))
+    return dx
+
+
+class ResidualBlockFn(torch.autograd.Function):
+    """ResidualBlock1d.forward (src/models/tdcn.py:107-147): returns (output or None, skip)."""
+
+    @staticmethod
+    def forward(ctx, x, dilation, causal, dual, eps, *params):
+        x = as_act(x.detach())
+        L = Layer(params, dual)
+        B, _, T = x.shape
+        skip = new_act(B, L.Sc, T, x.device)
+        out, saved = layer_forward(L, x, skip, False, dilation, causal, eps)
+        ctx.L, ctx.saved_acts, ctx.cfg = L, saved, (dilation, causal, eps)
+        ctx.params = params
+        if dual:
+            return out, skip
+        return None, skip
+
+    @staticmethod
+    def backward(ctx, dout, dskip):
+        dilation, causal, eps = ctx.cfg
+        L = ctx.L
+        x = ctx.saved_acts[0]
+        B, _, T = x.shape
+        if dskip is None:
+            dskip = new_act(B, L.Sc, T, x.device, zero=True)
+        dskip = as_act(dskip)
+        dout = as_act(dout) if dout is not None else None
+        sink = GradSink(ctx.params)
+        dx = layer_backward(L, ctx.saved_acts, dout, dskip, sink, dilation, causal, eps)
+        grads = sink.finish()
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ standalone norm
+class LayerNormFn(torch.autograd.Function):
+    """GlobalLayerNorm / CumulativeLayerNorm1d forward+backward (src/modules/norm.py:20-29, :58-95)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, causal):
+        shape = x.shape
+        x3 = as_act(x.detach().reshape(shape[0], shape[1], -1))
+        B, Cc, T = x3.shape
+        acc = Accum(B, T, causal, x3.device)
+        ops.norm_stats(x3, None, acc)
+        st = ops.finalize_stats(acc, B, Cc, T, eps, x3.device)
+        y = new_act(B, Cc, T, x3.device)
+        ops.norm_apply(x3, None, st, gamma.detach().reshape(-1), beta.detach().reshape(-1), y)
+        ctx.saved = (x3, st, gamma, beta, eps, causal, shape)
+        return y.reshape(shape) if len(shape) != 3 else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, st, gamma, beta, eps, causal, shape = ctx.saved
+        B, Cc, T = x3.shape
+        dy3 = as_act(dy.reshape(B, Cc, T))
+        g = gamma.detach().reshape(-1)
+        dgamma = torch.zeros_like(g)
+        dbeta = torch.zeros_like(g)
+        acc = Accum(B, T, causal, x3.device)
+        ops.norm_bwd_reduce(dy3, x3, None, st, g, acc, dgamma, dbeta)
+        ops.bwd_coefs(acc, st, B, Cc, T, eps)
+        dx = new_act(B, Cc, T, x3.device)
+        ops.norm_bwd_apply(dy3, x3, None, st, g, dx, None)
+        dx = dx.reshape(shape) if len(shape) != 3 else dx
+        return dx, dgamma.view(gamma.shape), dbeta.view(beta.shape), None, None
+
+
+# ------------------------------------------------------------------------------------------------ pointwise conv
+class Conv1x1Fn(torch.autograd.Function):
+    """nn.Conv1d(C_in, C_out, kernel_size=1) forward/backward on the MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = as_act(x.detach())
+        B, K, T = x.shape
+        M = weight.shape[0]
+        Wt = torch.empty((K, M), device=x.device, dtype=torch.float32)
+        ops.transpose(weight.detach().view(M, K), Wt, M)
+        y = new_act(B, M, T, x.device)
+        ops.gemm_nn(M, T, K, B, Wt, M, x, y, bias=None if bias is None else bias.detach())
+        ctx.saved = (x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved
+        B, K, T = x.shape
+        M = weight.shape[0]
+        dy = as_act(dy)
+        dx = new_act(B, K, T, x.device)
+        ops.gemm_nn(K, T, M, B, weight.detach().view(M, K), K, dy, dx)
+        dW = torch.zeros((M, K), device=x.device, dtype=torch.float32)
+        db = None if bias is None else torch.zeros((M,), device=x.device, dtype=torch.float32)
+        ops.gemm_nt(M, K, T, B, dy, x, dW, K, a_rowsum=db)
+        return dx, dW.view(weight.shape), db
+
+
+class DepthwiseFn(torch.autograd.Function):
+    """Plain depthwise nn.Conv1d(C, C, P, stride=1, dilation=d, groups=C) with explicit zero padding
+    (src/modules/conv.py:22,26)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dilation, pad_left, pad_right):
+        x = as_act(x.detach())
+        B, Cc, T = x.shape
+        P = weight.shape[-1]
+        Tout = T + pad_left + pad_right - (P - 1) * dilation
+        if Tout != T:
+            raise NotImplementedError("depthwise kernel supports 'same'-length output only "
+                                      "(pad_left + pad_right == (P-1)*dilation)")
+        y = new_act(B, Cc, T, x.device)
+        ops.dw_fwd(x, weight.detach().view(Cc, P), None if bias is None else bias.detach(), y, dilation, pad_left)
+        ctx.saved = (x, weight, bias, dilation, pad_left)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, dilation, pad_left = ctx.saved
+        B, Cc, T = x.shape
+        P = weight.shape[-1]
+        dy = as_act(dy)
+        dw = torch.zeros((Cc, P), device=x.device, dtype=torch.float32)
+        db = None if bias is None else torch.zeros((Cc,), device=x.device, dtype=torch.float32)
+        dx = new_act(B, Cc, T, x.device)
+        ops.dw_bwd(dy, x, weight.detach().view(Cc, P), dw, db, dx, dilation, pad_left)
+        return dx, dw.view(weight.shape), db, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ encoder / decoder
+def _enc_geometry(T, L, S):
+    padding = (S - (T - L) % S) % S                   # src/models/conv_tasnet.py:145
+    pad_left = padding // 2
+    Tf = (T + padding - L) // S + 1
+    return padding, pad_left, Tf
+
+
+class EncoderFn(torch.autograd.Function):
+    """Encoder.forward (src/models/filterbank.py:222-230) on an already padded (B, 1, T) input."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, relu):
+        B, C_in, T = x.shape
+        if C_in != 1:
+            raise NotImplementedError("HIP encoder supports in_channels == 1")
+        N, _, L = weight.shape
+        Tf = (T - L) // stride + 1
+        x2 = x.detach().reshape(B, T).contiguous().float()
+        w = new_act(B, N, Tf, x.device)
+        ops.encoder_fwd(x2, 0, weight.detach(), stride, relu, w)
+        ctx.saved = (x2, weight, stride, relu, w)
+        ctx.set_materialize_grads(False)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        x2, weight, stride, relu, w = ctx.saved
+        if dw is None:
+            return None, None, None, None
+        N, _, L = weight.shape
+        dW = torch.zeros((N, L), device=w.device, dtype=torch.float32)
+        dwt = new_act(w.shape[0], N, w.shape[2], w.device) if ctx.needs_input_grad[0] else None
+        ops.encoder_bwd(x2, 0, N, L, stride, relu, w, dW, dw_a=as_act(dw), dwt_out=dwt)
+        dx = None
+        if dwt is not None:   # transposed convolution of dwt with the same basis
+            B, T = x2.shape
+            dx = torch.zeros((B, 1, T), device=w.device, dtype=torch.float32)
+            ops.maskdecode_fwd(dwt, None, 1, weight.detach(), stride, dx, 0)
+        return dx, dW.view(weight.shape), None, None
+
+
+class DecoderFn(torch.autograd.Function):
+    """Decoder.forward (src/models/filterbank.py:245-247): ConvTranspose1d(N, 1, L, stride, bias=False)."""
+
+    @staticmethod
+    def forward(ctx, w, weight, stride):
+        w = as_act(w.detach())
+        B, N, Tf = w.shape
+        L = weight.shape[-1]
+        Tout = (Tf - 1) * stride + L
+        out = torch.empty((B, 1, Tout), device=w.device, dtype=torch.float32)
+        ops.maskdecode_fwd(w, None, 1, weight.detach(), stride, out, 0)
+        ctx.saved = (w, weight, stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w, weight, stride = ctx.saved
+        B, N, Tf = w.shape
+        L = weight.shape[-1]
+        dout = dout.contiguous().float()
+        dWd = torch.zeros((N, L), device=w.device, dtype=torch.float32)
+        dw = new_act(B, N, Tf, w.device)
+        ops.maskdecode_bwd(dout, 0, w, None, 1, weight.detach(), stride, False, None, dw, dWd)
+        return dw, dWd.view(weight.shape), None
+
+
+# ------------------------------------------------------------------------------------------------ whole model
+class ModelParams:
+    """Parameter tensors of a ConvTasNet in a fixed order for ConvTasNetFn.
+
+    order: enc_W, n0_gamma, n0_beta, Wb, bb, [layer params ...], a_sep, Wm, bm, dec_W"""
+
+    def __init__(self, tensors, cfg):
+        self.cfg = cfg
+        R, X = cfg["sep_num_blocks"], cfg["sep_num_layers"]
+        it = iter(tensors)
+        self.tensors = list(tensors)
+        self.enc_W, self.g0, self.be0, self.Wb, self.bb = (next(it) for _ in range(5))
+        self.layers = []
+        for r in range(R):
+            for l in range(X):
+                dual = not (r == R - 1 and l == X - 1)
+                n = len(Layer.NAMES_DUAL if dual else Layer.NAMES_SINGLE)
+                self.layers.append((Layer([next(it) for _ in range(n)], dual), 2 ** l))
+        self.a_sep, self.Wm, self.bm, self.dec_W = (next(it) for _ in range(4))
+
+
+def separator_forward(mp, w, st0_acc, eps, sigmoid=True):
+    """norm -> bottleneck -> TCN -> PReLU -> mask conv -> sigmoid (src/models/conv_tasnet.py:359-378).
+    w act (B, N, Tf) with its norm statistics already accumulated in st0_acc.  Returns mask, saved."""
+    cfg = mp.cfg
+    causal = cfg["causal"]
+    B, N, T = w.shape
+    dev = w.device
+    Bc = mp.Wb.shape[0]
+    st0 = ops.finalize_stats(st0_acc, B, N, T, eps, dev)
+    Wbt = torch.empty((N, Bc), device=dev, dtype=torch.float32)
+    ops.transpose(mp.Wb.detach().view(Bc, N), Wbt, Bc)
+    x = new_act(B, Bc, T, dev)
+    ops.gemm_nn(Bc, T, N, B, Wbt, Bc, w, x, xflags=XF_NORM, stat=st0, gamma=mp.g0.detach().view(-1),
+                beta=mp.be0.detach().view(-1), bias=mp.bb.detach())
+    Sc = mp.layers[0][0].Sc
+    skip = new_act(B, Sc, T, dev)
+    saved_layers = []
+    for i, (L, dil) in enumerate(mp.layers):
+        x_next, sv = layer_forward(L, x, skip, i > 0, dil, causal, eps)
+        saved_layers.append(sv)
+        x = x_next
+    M = mp.Wm.shape[0]
+    Wmt = torch.empty((Sc, M), device=dev, dtype=torch.float32)
+    ops.transpose(mp.Wm.detach().view(M, Sc), Wmt, M)
+    mask = new_act(B, M, T, dev)
+    ops.gemm_nn(M, T, Sc, B, Wmt, M, skip, mask, xflags=XF_PRELU, alpha=mp.a_sep.detach(), bias=mp.bm.detach(),
+                emode=EPI_SIGMOID if sigmoid else EPI_STORE)
+    return mask, (st0, skip, saved_layers)
+
+
+def separator_backward(mp, w, saved, dz, sink, eps):
+    """dz act (B, n_src*N, T): gradient w.r.t. the mask logits.  Returns dn0 (gradient w.r.t. the normalised
+    separator input, before the entry norm's backward) and the entry-norm Stat with c1/c2 filled."""
+    cfg = mp.cfg
+    causal = cfg["causal"]
+    st0, skip, saved_layers = saved
+    B, N, T = w.shape
+    dev = w.device
+    Bc = mp.Wb.shape[0]
+    Sc = mp.layers[0][0].Sc
+    M = mp.Wm.shape[0]
+    # mask conv: weight/bias gradient, input gradient through the separator PReLU
+    ops.gemm_nt(M, Sc, T, B, dz, skip, sink.g(mp.Wm).view(M, Sc), Sc, a_rowsum=sink.g(mp.bm), bflags=XF_PRELU,
+                b_alpha=mp.a_sep.detach())
+    dskip = new_act(B, Sc, T, dev)
+    ops.gemm_nn(Sc, T, M, B, mp.Wm.detach().view(M, Sc), Sc, dz, dskip, emode=EPI_PRELUBWD, E=skip,
+                ealpha=mp.a_sep.detach(), esums=sink.alpha_slot(mp.a_sep))
+    dout = None
+    for (L, dil), sv in zip(reversed(mp.layers), reversed(saved_layers)):
+        dout = layer_backward(L, sv, dout, dskip, sink, dil, causal, eps)
+    # separator bottleneck
+    dn0 = new_act(B, N, T, dev)
+    bacc0 = Accum(B, T, causal, dev)
+    ops.gemm_nn(N, T, Bc, B, mp.Wb.detach().view(Bc, N), N, dout, dn0, emode=EPI_NORMBWD, E=w, ealpha=None,
+                estat=st0, egamma=mp.g0.detach().view(-1), eacc=bacc0)
+    ops.gemm_nt(Bc, N, T, B, dout, w, sink.g(mp.Wb).view(Bc, N), N, a_rowsum=sink.g(mp.bb), bflags=XF_NORM,
+                b_stat=st0, b_gamma=mp.g0.detach().view(-1), b_beta=mp.be0.detach().view(-1))
+    ops.bwd_coefs(bacc0, st0, B, N, T, eps)
+    return dn0, st0
+
+
+class ConvTasNetFn(torch.autograd.Function):
+    """ConvTasNet.forward for trainable encoder/decoder, separable dilated TCN with PReLU + norm and a
+    sigmoid mask (src/models/conv_tasnet.py:116-171)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        mp = ModelParams(params, cfg)
+        B, C_in, T = x.shape
+        L, S = cfg["kernel_size"], cfg["stride"]
+        N, n_src = cfg["n_basis"], cfg["n_sources"]
+        eps, causal = cfg["eps"], cfg["causal"]
+        relu = cfg.get("enc_nonlinear") == "relu"
+        dev = x.device
+        padding, pad_left, Tf = _enc_geometry(T, L, S)
+        x2 = x.detach().reshape(B, T).contiguous().float()
+        w = new_act(B, N, Tf, dev)
+        acc0 = Accum(B, Tf, causal, dev)
+        ops.encoder_fwd(x2, pad_left, mp.enc_W.detach(), S, relu, w, acc0)
+        mask, saved = separator_forward(mp, w, acc0, eps)
+        out = torch.empty((B, n_src, T), device=dev, dtype=torch.float32)
+        ops.maskdecode_fwd(w, mask, n_src, mp.dec_W.detach(), S, out, pad_left)
+        ctx.mp, ctx.saved_acts = mp, (x2, w, mask, saved, pad_left, relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mp = ctx.mp
+        cfg = mp.cfg
+        x2, w, mask, saved, pad_left, relu = ctx.saved_acts
+        B, N, Tf = w.shape
+        L, S, n_src, eps = cfg["kernel_size"], cfg["stride"], cfg["n_sources"], cfg["eps"]
+        dev = w.device
+        sink = GradSink(mp.tensors, cfg.get("grad_flat"))
+        dout = dout.contiguous().float()
+        dz = new_act(B, n_src * N, Tf, dev)
+        dw_dec = new_act(B, N, Tf, dev)
+        ops.maskdecode_bwd(dout, pad_left, w, mask, n_src, mp.dec_W.detach(), S, True, dz, dw_dec,
+                           sink.g(mp.dec_W).view(N, L))
+        dn0, st0 = separator_backward(mp, w, saved, dz, sink, eps)
+        ops.encoder_bwd(x2, pad_left, N, L, S, relu, w, sink.g(mp.enc_W).view(N, L), dw_a=dw_dec, dn=dn0, stat=st0,
+                        gamma=mp.g0.detach().view(-1), dgamma=sink.g(mp.g0).view(-1), dbeta=sink.g(mp.be0).view(-1))
+        grads = sink.finish()
+        return (None, None) + tuple(grads)
+
+
+class SeparatorFn(torch.autograd.Function):
+    """Separator.forward up to the mask logits (src/models/conv_tasnet.py:370-374) on its own:
+    input (B, N, T') -> logits (B, n_src*N, T').  The mask non-linearity is applied by the caller."""
+
+    @staticmethod
+    def forward(ctx, w, cfg, *params):
+        # params: g0, be0, Wb, bb, layers..., a_sep, Wm, bm  (ModelParams order without encoder/decoder)
+        w = as_act(w.detach())
+        B, N, T = w.shape
+        mp = ModelParams((None,) + tuple(params) + (None,), cfg)
+        mp.tensors = list(params)
+        acc0 = Accum(B, T, cfg["causal"], w.device)
+        ops.norm_stats(w, None, acc0)
+        logits, saved = separator_forward(mp, w, acc0, cfg["eps"], sigmoid=False)
+        ctx.mp, ctx.saved_acts = mp, (w, saved)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dz):
+        mp = ctx.mp
+        cfg = mp.cfg
+        w, saved = ctx.saved_acts
+        B, N, T = w.shape
+        eps = cfg["eps"]
+        sink = GradSink(mp.tensors)
+        dn0, st0 = separator_backward(mp, w, saved, as_act(dz), sink, eps)
+        g0 = mp.g0.detach().view(-1)
+        scratch = Accum(B, T, cfg["causal"], w.device)
+        ops.norm_bwd_reduce(dn0, w, None, st0, g0, scratch, sink.g(mp.g0).view(-1), sink.g(mp.be0).view(-1))
+        dw = new_act(B, N, T, w.device)
+        ops.norm_bwd_apply(dn0, w, None, st0, g0, dw, None)
+        grads = sink.finish()
+        return (dw, None) + tuple(grads)

@@ -1,0 +1,388 @@
+"""Tensor-level wrappers over the C ABI of libctn_hip.so.
+
+Nothing here computes on the host or falls back to PyTorch kernels: each
+function checks layouts, fills the argument struct and enqueues HIP kernels on
+the current torch stream.  Activations are (B, C, T) fp32 views with unit time
+stride whose row and batch strides are multiples of 4 floats ("act" layout,
+see new_act); anything else is copied into that layout first.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (XF_PRELU, XF_NORM, XF_NORMBWD, EPI_STORE, EPI_STATS, EPI_HEADS, EPI_SIGMOID,  # noqa: F401
+                   EPI_PRELUBWD, EPI_NORMBWD, EPI_ADD)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CtnError("speech_amd operators run on the GPU only (got a {} tensor); "
+                                "there is no CPU path".format(t.device))
+
+
+def round4(n):
+    return (n + 3) // 4 * 4
+
+
+def new_act(B, Cc, T, device, zero=False):
+    """(B, C, T) view of a (B, C, ld) buffer, ld = T rounded up to 4 floats (16-byte rows)."""
+    ld = round4(T)
+    buf = (torch.zeros if zero else torch.empty)((B, Cc, ld), device=device, dtype=torch.float32)
+    return buf[:, :, :T]
+
+
+def is_act(x):
+    return (x.dim() == 3 and x.dtype == torch.float32 and x.is_cuda and x.stride(2) == 1
+            and x.stride(1) % 4 == 0 and x.stride(0) % 4 == 0 and x.stride(1) >= x.shape[2]
+            and x.data_ptr() % 16 == 0)
+
+
+def as_act(x):
+    if is_act(x):
+        return x
+    _require_cuda(x)
+    y = new_act(x.shape[0], x.shape[1], x.shape[2], x.device)
+    y.copy_(x)
+    return y
+
+
+class Stat:
+    """Layer-norm statistics: mean/rstd (and backward c1/c2) indexed [b*sb + t*st]."""
+
+    __slots__ = ("mean", "rstd", "c1", "c2", "sb", "st", "cln")
+
+    def __init__(self, mean, rstd, sb, st, cln):
+        self.mean, self.rstd, self.sb, self.st, self.cln = mean, rstd, sb, st, cln
+        self.c1 = self.c2 = None
+
+
+class Accum:
+    """Zeroed accumulators for one norm's statistics: double (B, 2) for gLN, float (B, 2, ld) for cLN."""
+
+    __slots__ = ("sums", "col", "ld")
+
+    def __init__(self, B, T, cln, device):
+        if cln:
+            self.ld = round4(T)
+            self.col = torch.zeros((B, 2, self.ld), device=device, dtype=torch.float32)
+            self.sums = None
+        else:
+            self.ld = 0
+            self.col = None
+            self.sums = torch.zeros((B, 2), device=device, dtype=torch.float64)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def transpose(src2d, dst, ldd, coff=0):
+    lib = _lib.load()
+    M, K = src2d.shape
+    _lib.check(lib.ctn_transpose(_ptr(src2d), M, K, _ptr(dst), ldd, coff, _stream()), "ctn_transpose")
+
+
+def norm_stats(x, alpha, acc):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    _lib.check(lib.ctn_norm_stats(_ptr(x), B, Cc, T, x.stride(1), _ptr(alpha), _ptr(acc.sums), _ptr(acc.col),
+                                  acc.ld, _stream()), "ctn_norm_stats")
+
+
+def finalize_stats(acc, B, Cc, T, eps, device):
+    """Accumulated sums -> Stat (mean, rstd)."""
+    lib = _lib.load()
+    if acc.col is not None:
+        ld = acc.ld
+        mean = torch.empty((B, ld), device=device, dtype=torch.float32)
+        rstd = torch.empty((B, ld), device=device, dtype=torch.float32)
+        _lib.check(lib.ctn_cln_finalize(_ptr(acc.col), B, Cc, T, ld, eps, _ptr(mean), _ptr(rstd), ld, _stream()),
+                   "ctn_cln_finalize")
+        return Stat(mean, rstd, ld, 1, True)
+    mean = torch.empty((B,), device=device, dtype=torch.float32)
+    rstd = torch.empty((B,), device=device, dtype=torch.float32)
+    _lib.check(lib.ctn_gln_finalize(_ptr(acc.sums), B, float(Cc) * float(T), eps, _ptr(mean), _ptr(rstd), _stream()),
+               "ctn_gln_finalize")
+    return Stat(mean, rstd, 1, 0, False)
+
+
+def bwd_coefs(acc, stat, B, Cc, T, eps):
+    """Backward sums -> stat.c1, stat.c2."""
+    lib = _lib.load()
+    stat.c1 = torch.empty_like(stat.mean)
+    stat.c2 = torch.empty_like(stat.mean)
+    if stat.cln:
+        _lib.check(lib.ctn_cln_bwd_coefs(_ptr(acc.col), acc.ld, _ptr(stat.mean), _ptr(stat.rstd), stat.sb, B, Cc, T,
+                                         eps, _ptr(stat.c1), _ptr(stat.c2), _stream()), "ctn_cln_bwd_coefs")
+    else:
+        _lib.check(lib.ctn_gln_bwd_coefs(_ptr(acc.sums), _ptr(stat.rstd), B, float(Cc) * float(T), _ptr(stat.c1),
+                                         _ptr(stat.c2), _stream()), "ctn_gln_bwd_coefs")
+    return stat
+
+
+def norm_apply(x, alpha, stat, gamma, beta, y):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    _lib.check(lib.ctn_norm_apply(_ptr(x), B, Cc, T, x.stride(1), _ptr(alpha), _ptr(stat.mean), _ptr(stat.rstd),
+                                  stat.sb, stat.st, _ptr(gamma), _ptr(beta), _ptr(y), y.stride(1), _stream()),
+               "ctn_norm_apply")
+
+
+def norm_bwd_reduce(dn, x, alpha, stat, gamma, acc, dgamma, dbeta):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    _lib.check(lib.ctn_norm_bwd_reduce(_ptr(dn), dn.stride(1), _ptr(x), x.stride(1), B, Cc, T, _ptr(alpha),
+                                       _ptr(stat.mean), _ptr(stat.rstd), stat.sb, stat.st, _ptr(gamma),
+                                       _ptr(acc.sums), _ptr(acc.col), acc.ld, _ptr(dgamma), _ptr(dbeta), _stream()),
+               "ctn_norm_bwd_reduce")
+
+
+def norm_bwd_apply(dn, x, alpha, stat, gamma, dx, dalpha):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    _lib.check(lib.ctn_norm_bwd_apply(_ptr(dn), dn.stride(1), _ptr(x), x.stride(1), B, Cc, T, _ptr(alpha),
+                                      _ptr(stat.mean), _ptr(stat.rstd), _ptr(stat.c1), _ptr(stat.c2), stat.sb,
+                                      stat.st, _ptr(gamma), _ptr(dx), dx.stride(1), _ptr(dalpha), _stream()),
+               "ctn_norm_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------------------ GEMMs
+def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, xflags=0, X2=None, alpha=None,
+            stat=None, gamma=None, beta=None, bias=None, bias2=None, emode=EPI_STORE, Mo=0, R=None, Y2=None,
+            accumulate=False, ealpha=None, eacc=None, E=None, estat=None, egamma=None, esums=None):
+    """Y[b] = A(k-major) . xform(X[b]); see ctn_gemm_nn in include/ctn.h.  X/Xb/X2/Y/Y2/R/E are act views."""
+    lib = _lib.load()
+    a = _lib.GemmNNArgs()
+    a.M, a.T, a.K, a.batch = M, T, K, batch
+    a.A, a.lda = _ptr(A), lda
+    a.A2, a.lda2 = _ptr(A2), lda2
+    a.K1 = K if K1 is None else K1
+    a.xflags = xflags
+    a.bias, a.bias2 = _ptr(bias), _ptr(bias2)
+    a.X, a.ldx, a.xbs = _ptr(X), X.stride(1), X.stride(0)
+    if Xb is not None:
+        a.Xb, a.ldxb, a.xbbs = _ptr(Xb), Xb.stride(1), Xb.stride(0)
+    if X2 is not None:
+        a.X2, a.ldx2, a.x2bs = _ptr(X2), X2.stride(1), X2.stride(0)
+    a.alpha = _ptr(alpha)
+    if stat is not None:
+        a.mean, a.rstd, a.c1, a.c2 = _ptr(stat.mean), _ptr(stat.rstd), _ptr(stat.c1), _ptr(stat.c2)
+        a.ssb, a.sst = stat.sb, stat.st
+    a.gamma, a.beta = _ptr(gamma), _ptr(beta)
+    a.Y, a.ldy, a.ybs = _ptr(Y), Y.stride(1), Y.stride(0)
+    a.emode, a.Mo = emode, Mo
+    if R is not None:
+        a.R, a.ldr, a.rbs = _ptr(R), R.stride(1), R.stride(0)
+    if Y2 is not None:
+        a.Y2, a.ldy2, a.y2bs = _ptr(Y2), Y2.stride(1), Y2.stride(0)
+    a.accumulate = 1 if accumulate else 0
+    a.ealpha = _ptr(ealpha)
+    if eacc is not None:
+        a.esums = _ptr(eacc.sums)
+        a.ecol, a.ecol_bs, a.ecol_ld = _ptr(eacc.col), 2 * eacc.ld, eacc.ld
+    if esums is not None:
+        a.esums = _ptr(esums)
+    if E is not None:
+        a.E, a.lde, a.ebs = _ptr(E), E.stride(1), E.stride(0)
+    if estat is not None:
+        a.emean, a.erstd, a.essb, a.esst = _ptr(estat.mean), _ptr(estat.rstd), estat.sb, estat.st
+    a.egamma = _ptr(egamma)
+    _lib.check(lib.ctn_gemm_nn(C.byref(a), _stream()), "ctn_gemm_nn")
+
+
+def pick_kchunk(T, batch, tiles):
+    """Time steps per wgrad block: enough blocks to fill 256 CUs a few times over, chunks >= 256 frames."""
+    target_blocks = 1024
+    chunks = max(1, target_blocks // max(1, batch * tiles))
+    k = (T + chunks - 1) // chunks
+    k = max(256, (k + 31) // 32 * 32)
+    return k
+
+
+def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=0, aflags=0, A2=None,
+            a_alpha=None, a_stat=None, a_gamma=None, a_rowsum=None, a_rowsum2=None, a_dalpha=None, bflags=0,
+            b_alpha=None, b_stat=None, b_gamma=None, b_beta=None, kchunk=None):
+    """C[m][n] += sum_b,t xformA(A)[b][m][t] * xformB(B)[b][n][t]; see ctn_gemm_nt in include/ctn.h."""
+    lib = _lib.load()
+    a = _lib.GemmNTArgs()
+    a.M, a.N, a.T, a.batch = M, N, T, batch
+    a.M1 = M if M1 is None else M1
+    if A is not None:
+        a.A, a.lda, a.abs_ = _ptr(A), A.stride(1), A.stride(0)
+    if Ab is not None:
+        a.Ab, a.ldab, a.abbs = _ptr(Ab), Ab.stride(1), Ab.stride(0)
+    a.aflags = aflags
+    if A2 is not None:
+        a.A2, a.lda2, a.a2bs = _ptr(A2), A2.stride(1), A2.stride(0)
+    a.a_alpha = _ptr(a_alpha)
+    if a_stat is not None:
+        a.a_mean, a.a_rstd, a.a_c1, a.a_c2 = _ptr(a_stat.mean), _ptr(a_stat.rstd), _ptr(a_stat.c1), _ptr(a_stat.c2)
+        a.a_ssb, a.a_sst = a_stat.sb, a_stat.st
+    a.a_gamma = _ptr(a_gamma)
+    a.a_rowsum, a.a_rowsum2, a.a_dalpha = _ptr(a_rowsum), _ptr(a_rowsum2), _ptr(a_dalpha)
+    a.B, a.ldb, a.bbs = _ptr(B), B.stride(1), B.stride(0)
+    a.bflags = bflags
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    a.kchunk = kchunk or pick_kchunk(T, batch, tiles)
+    a.b_alpha = _ptr(b_alpha)
+    if b_stat is not None:
+        a.b_mean, a.b_rstd, a.b_ssb, a.b_sst = _ptr(b_stat.mean), _ptr(b_stat.rstd), b_stat.sb, b_stat.st
+    a.b_gamma, a.b_beta = _ptr(b_gamma), _ptr(b_beta)
+    a.C, a.ldc = _ptr(Cout), ldc
+    a.C2, a.ldc2 = _ptr(C2), ldc2
+    _lib.check(lib.ctn_gemm_nt(C.byref(a), _stream()), "ctn_gemm_nt")
+
+
+# ------------------------------------------------------------------------------------------------ depthwise
+def dw_fwd(x, w, bias, y, dilation, pad_left, *, xflags=0, alpha_in=None, stat=None, gamma=None, beta=None,
+           alpha_out=None, acc=None, stats=True):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    a = _lib.DwFwdArgs()
+    a.batch, a.C, a.T, a.P = B, Cc, T, w.shape[-1]
+    a.dilation, a.pad_left, a.xflags = dilation, pad_left, xflags
+    a.cln = 1 if (acc is not None and acc.col is not None) else 0
+    a.x, a.ldx, a.xbs = _ptr(x), x.stride(1), x.stride(0)
+    a.alpha_in = _ptr(alpha_in)
+    if stat is not None:
+        a.mean, a.rstd, a.ssb, a.sst = _ptr(stat.mean), _ptr(stat.rstd), stat.sb, stat.st
+    a.gamma, a.beta = _ptr(gamma), _ptr(beta)
+    a.w, a.bias = _ptr(w), _ptr(bias)
+    a.y, a.ldy, a.ybs = _ptr(y), y.stride(1), y.stride(0)
+    if acc is not None:
+        a.alpha_out = _ptr(alpha_out)
+        a.esums = _ptr(acc.sums)
+        a.ecol, a.ecol_ld = _ptr(acc.col), acc.ld
+    _lib.check(lib.ctn_dw_fwd(C.byref(a), _stream()), "ctn_dw_fwd")
+
+
+def dw_bwd(dn2, x, w, dw, dbias, dx, dilation, pad_left, *, xflags=0, alpha1=None, stat1=None, gamma1=None,
+           beta1=None, dgamma1=None, dbeta1=None, iacc=None, y2=None, alpha2=None, stat2=None, gamma2=None,
+           dgamma2=None, dbeta2=None, dalpha2=None):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    a = _lib.DwBwdArgs()
+    a.batch, a.C, a.T, a.P = B, Cc, T, w.shape[-1]
+    a.dilation, a.pad_left, a.xflags = dilation, pad_left, xflags
+    a.oflags = XF_NORMBWD if stat2 is not None else 0
+    cln = (stat1 is not None and stat1.cln) or (stat2 is not None and stat2.cln)
+    a.cln = 1 if cln else 0
+    a.dn2, a.lddn2, a.dn2bs = _ptr(dn2), dn2.stride(1), dn2.stride(0)
+    if y2 is not None:
+        a.y2, a.ldy2, a.y2bs = _ptr(y2), y2.stride(1), y2.stride(0)
+    a.alpha2 = _ptr(alpha2)
+    if stat2 is not None:
+        a.mean2, a.rstd2, a.c1_2, a.c2_2 = _ptr(stat2.mean), _ptr(stat2.rstd), _ptr(stat2.c1), _ptr(stat2.c2)
+        a.ssb2, a.sst2 = stat2.sb, stat2.st
+    a.gamma2 = _ptr(gamma2)
+    a.dgamma2, a.dbeta2, a.dalpha2 = _ptr(dgamma2), _ptr(dbeta2), _ptr(dalpha2)
+    a.x, a.ldx, a.xbs = _ptr(x), x.stride(1), x.stride(0)
+    a.alpha1 = _ptr(alpha1)
+    if stat1 is not None:
+        a.mean1, a.rstd1, a.ssb1, a.sst1 = _ptr(stat1.mean), _ptr(stat1.rstd), stat1.sb, stat1.st
+    a.gamma1, a.beta1 = _ptr(gamma1), _ptr(beta1)
+    a.w, a.dw, a.dbias = _ptr(w), _ptr(dw), _ptr(dbias)
+    a.dx, a.lddx, a.dxbs = _ptr(dx), dx.stride(1), dx.stride(0)
+    if iacc is not None:
+        a.isums, a.icol, a.icol_ld = _ptr(iacc.sums), _ptr(iacc.col), iacc.ld
+    a.dgamma1, a.dbeta1 = _ptr(dgamma1), _ptr(dbeta1)
+    _lib.check(lib.ctn_dw_bwd(C.byref(a), _stream()), "ctn_dw_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ codec
+def encoder_fwd(x2d, pad_left, W, S, relu, w_out, acc=None):
+    """x2d (B, Tin) unit stride; W (N, 1, L); w_out act (B, N, Tf)."""
+    lib = _lib.load()
+    B, Tin = x2d.shape
+    N, L = W.shape[0], W.shape[-1]
+    Tf = w_out.shape[2]
+    sums = col = None
+    ld = 0
+    if acc is not None:
+        sums, col, ld = acc.sums, acc.col, acc.ld
+    _lib.check(lib.ctn_encoder_fwd(_ptr(x2d), x2d.stride(0), Tin, pad_left, B, _ptr(W), N, L, S, 1 if relu else 0,
+                                   _ptr(w_out), Tf, w_out.stride(1), _ptr(sums), _ptr(col), ld, _stream()),
+               "ctn_encoder_fwd")
+
+
+def encoder_bwd(x2d, pad_left, N, L, S, relu, w, dW, *, dw_a=None, dn=None, stat=None, gamma=None, dgamma=None,
+                dbeta=None, dwt_out=None):
+    lib = _lib.load()
+    B, Tin = x2d.shape
+    Tf = w.shape[2]
+    st = stat
+    _lib.check(lib.ctn_encoder_bwd(
+        _ptr(x2d), x2d.stride(0), Tin, pad_left, B, N, L, S, 1 if relu else 0, _ptr(w), Tf, w.stride(1),
+        _ptr(dw_a), dw_a.stride(1) if dw_a is not None else 0, _ptr(dn), dn.stride(1) if dn is not None else 0,
+        _ptr(st.mean) if st else None, _ptr(st.rstd) if st else None, _ptr(st.c1) if st else None,
+        _ptr(st.c2) if st else None, st.sb if st else 0, st.st if st else 0, _ptr(gamma), _ptr(dW), _ptr(dgamma),
+        _ptr(dbeta), _ptr(dwt_out), dwt_out.stride(1) if dwt_out is not None else 0, _stream()), "ctn_encoder_bwd")
+
+
+def maskdecode_fwd(w, mask, n_src, Wd, S, out, trim_left):
+    """w act (B, N, Tf); mask act (B, n_src*N, Tf) or None; out (B, n_src, Tout) unit stride."""
+    lib = _lib.load()
+    B, N, Tf = w.shape
+    L = Wd.shape[-1]
+    _lib.check(lib.ctn_maskdecode_fwd(_ptr(w), w.stride(1), _ptr(mask), mask.stride(1) if mask is not None else 0, B,
+                                      n_src, N, Tf, _ptr(Wd), L, S, _ptr(out), out.stride(1), out.stride(0),
+                                      out.shape[2], trim_left, _stream()), "ctn_maskdecode_fwd")
+
+
+def maskdecode_bwd(dout, trim_left, w, mask, n_src, Wd, S, sigmoid_bwd, dz, dw_dec, dWd):
+    lib = _lib.load()
+    B, N, Tf = w.shape
+    L = Wd.shape[-1]
+    _lib.check(lib.ctn_maskdecode_bwd(_ptr(dout), dout.stride(1), dout.stride(0), dout.shape[2], trim_left, _ptr(w),
+                                      w.stride(1), _ptr(mask), mask.stride(1) if mask is not None else 0, B, n_src, N,
+                                      Tf, _ptr(Wd), L, S, 1 if sigmoid_bwd else 0, _ptr(dz),
+                                      dz.stride(1) if dz is not None else 0, _ptr(dw_dec),
+                                      dw_dec.stride(1) if dw_dec is not None else 0, _ptr(dWd), _stream()),
+               "ctn_maskdecode_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ loss / optimizer
+def pit_sisdr_fwd(est, tgt, eps, fixed_perm=False):
+    """est, tgt (B, S, T) unit time stride, same strides.  Returns pair, loss_b, perm (int64), coef."""
+    lib = _lib.load()
+    B, S, T = est.shape
+    dev = est.device
+    work = torch.zeros((B, 2 * S * S + S), device=dev, dtype=torch.float64)
+    pair = torch.empty((B, S, S), device=dev, dtype=torch.float32)
+    loss_b = torch.empty((B,), device=dev, dtype=torch.float32)
+    perm = torch.empty((B, S), device=dev, dtype=torch.int64)
+    coef = torch.empty((B, S, 2), device=dev, dtype=torch.float32)
+    _lib.check(lib.ctn_pit_sisdr_fwd(_ptr(est), _ptr(tgt), B, S, T, est.stride(1), est.stride(0), eps,
+                                     1 if fixed_perm else 0, _ptr(work),
+                                     _ptr(pair), _ptr(loss_b), _ptr(perm), _ptr(coef), _stream()),
+               "ctn_pit_sisdr_fwd")
+    return pair, loss_b, perm, coef
+
+
+def pit_sisdr_bwd(est, tgt, perm, coef, gscale, gs_bstride, gs_istride):
+    lib = _lib.load()
+    B, S, T = est.shape
+    dest = torch.empty((B, S, T), device=est.device, dtype=torch.float32)
+    _lib.check(lib.ctn_pit_sisdr_bwd(_ptr(est), _ptr(tgt), B, S, T, est.stride(1), est.stride(0), _ptr(perm),
+                                     _ptr(coef), _ptr(gscale), gs_bstride, gs_istride, _ptr(dest), dest.stride(1), dest.stride(0),
+                                     _stream()), "ctn_pit_sisdr_bwd")
+    return dest
+
+
+def sumsq(g, acc):
+    lib = _lib.load()
+    _lib.check(lib.ctn_sumsq(_ptr(g), g.numel(), _ptr(acc), _stream()), "ctn_sumsq")
+
+
+def adam_step(p, g, m, v, sumsq_acc, max_norm, grad_scale, lr, beta1, beta2, eps, step):
+    lib = _lib.load()
+    _lib.check(lib.ctn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_acc),
+                                 float(max_norm or 0.0), float(grad_scale), lr, beta1, beta2, eps, step, _stream()),
+               "ctn_adam_step")

@@ -1,0 +1,267 @@
+"""Module-level parity on the GPU: the drop-in modules (HIP kernels underneath) against the golden vectors
+the reference produced (tests/golden) and against the CPU oracle on the same seeded inputs.
+
+Tolerances: rel 1e-4 on waveforms, loss and gradients (the bar BASELINE.json states), permutation indices
+bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import convtasnet_oracle as O
+from conftest import assert_close, assert_grad_close, rel_l2, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def load_state(module, sd):
+    module.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return module.to(dev())
+
+
+def test_norm_modules_golden(golden):
+    from speech_amd.modules.norm import GlobalLayerNorm, CumulativeLayerNorm1d
+    g = golden("norm")
+    inp = cases.norm_inputs()
+    for kind, cls in (("gln", GlobalLayerNorm), ("cln", CumulativeLayerNorm1d)):
+        mod = load_state(cls(8), cases.norm_params(kind))
+        x = inp[kind].to(dev()).requires_grad_(True)
+        y = mod(x)
+        y.backward(inp["gy"].to(dev()))
+        torch.cuda.synchronize()
+        assert_close(y, g[kind + "_y"], TOL, kind + " y")
+        assert_close(x.grad, g[kind + "_dx"], TOL, kind + " dx")
+        for k, p in mod.named_parameters():
+            assert_close(p.grad, g["{}_d_{}".format(kind, k)], TOL, kind + " d" + k)
+    mod = load_state(GlobalLayerNorm(8), cases.norm_params("gln"))
+    assert_close(mod(torch.zeros(1, 8, 50, device=dev())), g["gln_zero_y"], TOL, "gln zero")
+    mod = load_state(CumulativeLayerNorm1d(8), cases.norm_params("cln"))
+    assert_close(mod(inp["x4"].to(dev())), g["cln4_y"], TOL, "cln 4-D")
+
+
+@pytest.mark.parametrize("name,dil,causal,dual", cases.RESBLOCK_CASES)
+def test_resblock_golden(golden, name, dil, causal, dual):
+    from speech_amd.models.tdcn import ResidualBlock1d
+    g = golden("resblock")
+    d = cases.RESBLOCK_DIMS
+    mod = ResidualBlock1d(d["Bc"], hidden_channels=d["H"], skip_channels=d["Sc"], kernel_size=3, stride=1,
+                          dilation=dil, separable=True, causal=causal, nonlinear="prelu", norm=True, dual_head=dual)
+    load_state(mod, cases.resblock_state(causal, dual))
+    x, g_skip, g_out = cases.resblock_inputs(dual)
+    x = x.to(dev()).requires_grad_(True)
+    out, skip = mod(x)
+    loss = (skip * g_skip.to(dev())).sum()
+    if dual:
+        loss = loss + (out * g_out.to(dev())).sum()
+        assert_close(out, g[name + "_out"], TOL, "out")
+    else:
+        assert out is None
+    loss.backward()
+    torch.cuda.synchronize()
+    assert_close(skip, g[name + "_skip"], TOL, "skip")
+    assert_close(x.grad, g[name + "_dx"], TOL, "dx")
+    for k, p in mod.named_parameters():
+        assert_close(p.grad, g["{}_d_{}".format(name, k)], TOL, "d" + k)
+
+
+@pytest.mark.parametrize("name", ["rand2", "rand3", "tie", "swap", "silent"])
+def test_pit_golden(golden, name):
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    g = golden("pit")
+    est = torch.from_numpy(g[name + "_est"]).to(dev()).requires_grad_(True)
+    tgt = torch.from_numpy(g[name + "_tgt"]).to(dev())
+    crit = PIT1d(NegSISDR(), est.shape[1])
+    loss_b, perm_b = crit(est, tgt, batch_mean=False)
+    loss, perm = crit(est, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert perm.dtype == torch.int64
+    assert np.array_equal(perm.cpu().numpy(), g[name + "_perm"])
+    assert np.array_equal(perm_b.cpu().numpy(), g[name + "_perm"])
+    assert_close(loss_b, g[name + "_loss_b"], TOL, "loss_b")
+    assert_close(loss, g[name + "_loss"], TOL, "loss")
+    assert_close(est.grad, g[name + "_dest"], TOL, "dest")
+
+
+def test_sisdr_criteria_golden(golden):
+    from speech_amd.criterion.sdr import SISDR, NegSISDR, sisdr
+    g = golden("pit")
+    est = torch.from_numpy(g["rand2_est"]).to(dev())
+    tgt = torch.from_numpy(g["rand2_tgt"]).to(dev())
+    assert_close(SISDR()(est, tgt, batch_mean=False), g["sisdr_rand2"], TOL, "SISDR")
+    assert_close(NegSISDR()(est, tgt, batch_mean=False), -g["sisdr_rand2"], TOL, "NegSISDR")
+    ref = O.sisdr(est.cpu().double(), tgt.cpu().double())
+    assert_close(sisdr(est, tgt), ref, TOL, "sisdr (B,S,T)")
+    assert_close(sisdr(est[:, 0], tgt[:, 0]), ref[:, 0], TOL, "sisdr (B,T)")
+    e = est.clone().requires_grad_(True)
+    NegSISDR()(e, tgt).backward()
+    ec = est.cpu().double().requires_grad_(True)
+    O.neg_sisdr(ec, tgt.cpu().double()).backward()
+    assert_close(e.grad, ec.grad, TOL, "NegSISDR grad")
+
+
+def build(cfg):
+    from speech_amd.models.conv_tasnet import ConvTasNet
+    return ConvTasNet(cfg["n_basis"], cfg["kernel_size"], stride=cfg["stride"], enc_basis="trainable",
+                      dec_basis="trainable", enc_nonlinear=cfg["enc_nonlinear"],
+                      sep_hidden_channels=cfg["sep_hidden_channels"],
+                      sep_bottleneck_channels=cfg["sep_bottleneck_channels"],
+                      sep_skip_channels=cfg["sep_skip_channels"], sep_kernel_size=cfg["sep_kernel_size"],
+                      sep_num_blocks=cfg["sep_num_blocks"], sep_num_layers=cfg["sep_num_layers"], dilated=True,
+                      separable=True, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear=cfg["mask_nonlinear"],
+                      causal=cfg["causal"], n_sources=cfg["n_sources"])
+
+
+def _e2e(golden, name, cfg, full, grad_tol=TOL):
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    g = golden(name)
+    batch, T = int(g["batch"]), int(g["T"])
+    model = load_state(build(cfg), cases.e2e_state(cfg))
+    mixture, sources = cases.e2e_batch(cfg, batch, T, 0)
+    out = model(mixture.to(dev()))
+    loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(perm.cpu().numpy(), g["perm"])
+    assert_close(loss, g["loss"], TOL, "loss")
+    assert_close(out[..., ::8], g["out"], TOL, "out")
+    for k, p in model.named_parameters():
+        if full:
+            assert_grad_close(p.grad, g["grad." + k], "grad " + k)
+        else:   # paper-size fixtures hold sum, abs-sum and 16 strided samples per gradient tensor
+            # Scalar PReLU-slope gradients are sums with heavy cancellation through up to 24 kinked layers:
+            # measured against a float64 run, the reference's fp32 values are off by up to 1.0e-2 and this
+            # build's by up to 9.0e-3 (tools/diag_paper_alpha.py), hence the 3e-2 bound for them.
+            cs, ref = cases.checksum(p.grad), g["gradsum." + k]
+            tol = 3e-2 if p.numel() == 1 else 2e-3
+            assert abs(cs[1] - ref[1]) <= tol * ref[1], "grad abs-sum " + k
+            assert abs(cs[0] - ref[0]) <= tol * ref[1], "grad sum " + k
+            assert_close(cs[2:], ref[2:], max(tol, 1e-2), "grad samples " + k)
+    return model, g
+
+
+def test_e2e_small_golden(golden):
+    _e2e(golden, "e2e_small", O.CONFIG_SMALL, True)
+
+
+def test_e2e_small_causal3_golden(golden):
+    cfg = dict(O.CONFIG_SMALL, causal=True, n_sources=3, enc_nonlinear="relu")
+    _e2e(golden, "e2e_small_causal3", cfg, True)
+
+
+def test_e2e_paper_golden(golden):
+    _e2e(golden, "e2e_paper", O.CONFIG_PAPER, False)
+
+
+def test_e2e_paper_causal3_golden(golden):
+    _e2e(golden, "e2e_paper_causal3", O.CONFIG_CAUSAL3, False)
+
+
+def test_train_two_steps_golden(golden):
+    """FlatTrainer (fused clip + Adam on flat buffers) against the reference's post-step parameters."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    from speech_amd.trainer import FlatTrainer
+    cfg = O.CONFIG_SMALL
+    g = golden("e2e_small")
+    model = load_state(build(cfg), cases.e2e_state(cfg))
+    tr = FlatTrainer(model, PIT1d(NegSISDR(), 2), lr=1e-3, max_norm=5.0)
+    for step in range(2):
+        mixture, sources = cases.e2e_batch(cfg, int(g["batch"]), int(g["T"]), step)
+        loss, _ = tr.step(mixture.to(dev()), sources.to(dev()))
+        torch.cuda.synchronize()
+        if step == 1:
+            assert_close(loss, g["loss_step1"], TOL, "loss step 1")
+        for k, v in model.state_dict().items():
+            ref = g["param_step{}.{}".format(step + 1, k)]
+            # Adam's first steps move every weight by ~lr*sign(g): where |g| is at rounding level the sign,
+            # hence 2*lr per step, is arbitrary; everything else must agree to 1e-4
+            diff = (v.cpu() - torch.from_numpy(ref)).abs()
+            assert diff.max().item() <= 2.1e-3 * (step + 1), "param {} step {}: max".format(k, step + 1)
+            assert (diff > 1e-4).float().mean().item() <= 0.02, "param {} step {}: too many".format(k, step + 1)
+
+
+def test_smooth_network_gradients_vs_float64():
+    """With every PReLU slope at 1 (and a linear encoder) the network has no kinks, so ALL gradients are
+    held to the strict max-norm bar against a float64 run of the oracle (dalpha included: its integrand
+    min(y, 0) is continuous)."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    for cfg, T in ((O.CONFIG_SMALL, 16000), (dict(O.CONFIG_SMALL, causal=True, n_sources=3), 16000),
+                   (O.CONFIG_PAPER, 6000)):
+        sd = cases.e2e_state(cfg)
+        for k in sd:
+            if k.endswith("nonlinear1d.weight") or k.endswith("prelu.weight"):
+                sd[k].fill_(1.0)
+        mixture, sources = cases.e2e_batch(cfg, 2, T, 5)
+        _, perm64, out64, g64 = O.loss_and_grads(mixture.double(), sources.double(),
+                                                 {k: v.double() for k, v in sd.items()}, cfg)
+        model = load_state(build(cfg), sd)
+        out = model(mixture.to(dev()))
+        loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(perm.cpu(), perm64)
+        assert_close(out, out64, TOL, "out")
+        for k, p in model.named_parameters():
+            assert_close(p.grad, g64[k], TOL, "smooth grad " + k)
+
+
+def test_extract_latent_matches_forward():
+    """The modular path (encoder -> separator -> mask product -> decoder) equals the fused forward and the
+    oracle's latent."""
+    cfg = O.CONFIG_SMALL
+    sd = cases.e2e_state(cfg)
+    model = load_state(build(cfg), sd)
+    mixture, _ = cases.e2e_batch(cfg, 2, 4005, 0)
+    out_f = model(mixture.to(dev()))
+    out_m, latent = model.extract_latent(mixture.to(dev()))
+    ref_out, ref_lat = O.conv_tasnet_forward(mixture, sd, cfg, return_latent=True)
+    torch.cuda.synchronize()
+    assert_close(out_f, ref_out, TOL, "fused out")
+    assert_close(out_m, ref_out, TOL, "modular out")
+    assert_close(latent, ref_lat, TOL, "latent")
+    # gradients flow through the modular path as well
+    x = mixture.to(dev())
+    out_m, latent = model.extract_latent(x)
+    (out_m.sum() + latent.sum() * 1e-3).backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o, l = O.conv_tasnet_forward(mixture, params, cfg, return_latent=True)
+    grads = torch.autograd.grad(o.sum() + l.sum() * 1e-3, list(params.values()))
+    for (k, p), gr in zip(model.named_parameters(), grads):
+        assert_grad_close(p.grad, gr, "modular grad " + k)
+
+
+def test_full_size_properties():
+    """Paper config at the benchmark's full size (batch 4, 4 s): size-independent properties."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    cfg = O.CONFIG_PAPER
+    model = load_state(build(cfg), cases.e2e_state(cfg))
+    crit = PIT1d(NegSISDR(), 2)
+    mixture, sources = cases.e2e_batch(cfg, 4, 32000, 3)
+    mixture, sources = mixture.to(dev()), sources.to(dev())
+    out = model(mixture)
+    loss, perm = crit(out, sources)
+    assert out.shape == (4, 2, 32000) and torch.isfinite(out).all()
+    # determinism of the forward (no atomics on the forward data path other than statistics)
+    out2 = model(mixture)
+    assert_close(out2, out, 1e-6, "forward repeatability")
+    # batch independence: every op on the path is per-utterance
+    out_single = model(mixture[1:2])
+    assert_close(out_single, out[1:2], 1e-5, "batch independence")
+    # permutation equivariance of PIT: swapping the targets swaps the chosen permutation, same loss
+    loss_s, perm_s = crit(out, sources[:, [1, 0]])
+    assert_close(loss_s, loss, 1e-6, "PIT loss under target swap")
+    assert torch.equal(perm_s, 1 - perm)
+    # SI-SDR is invariant to the scale of the estimate
+    loss_k, perm_k = crit(out * 3.0, sources)
+    assert_close(loss_k, loss, 1e-5, "scale invariance")
+    assert torch.equal(perm_k, perm)

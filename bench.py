@@ -1,0 +1,228 @@
+"""Benchmark: Conv-TasNet training utterances/s (paper config, 2 speakers, 4 s @ 8 kHz) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward -> PIT SI-SDR -> backward -> gradient all-reduce (N > 1) -> clip(5) -> Adam(1e-3) on one
+synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.  Weak scaling: the per-GPU batch is
+fixed, value = utterances all ranks processed / max-over-ranks time.
+
+The line also carries
+  roofline      live HIP-event timing of the dominant kernel (the f32-MFMA pointwise-conv GEMM) over one
+                instrumented step: algorithmic FLOPs of its launches / their summed duration, vs the 157.3
+                TFLOP/s dense f32 matrix peak of MI355X;
+  roofline_hbm  the same for the fused depthwise kernels against the 8 TB/s HBM3E peak
+                (algorithmic bytes: forward 2 x H x T' x 4, backward 4 x H x T' x 4 per utterance and layer);
+  cpu_baseline  the CPU oracle (a PyTorch restatement of the reference's step) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PAPER = dict(n_basis=512, kernel_size=16, stride=8, enc_nonlinear=None, sep_hidden_channels=512,
+             sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3, sep_num_blocks=3,
+             sep_num_layers=8, mask_nonlinear="sigmoid", causal=False, n_sources=2, eps=1e-12)
+T_SAMPLES = 32000          # 4 s at 8 kHz
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(cfg, device):
+    from speech_amd.models.conv_tasnet import ConvTasNet
+    torch.manual_seed(111)     # the reference recipes' seed (egs/wsj0-mix/conv-tasnet/train.sh:59)
+    m = ConvTasNet(cfg["n_basis"], cfg["kernel_size"], stride=cfg["stride"], enc_basis="trainable",
+                   dec_basis="trainable", enc_nonlinear=cfg["enc_nonlinear"],
+                   sep_hidden_channels=cfg["sep_hidden_channels"],
+                   sep_bottleneck_channels=cfg["sep_bottleneck_channels"],
+                   sep_skip_channels=cfg["sep_skip_channels"], sep_kernel_size=cfg["sep_kernel_size"],
+                   sep_num_blocks=cfg["sep_num_blocks"], sep_num_layers=cfg["sep_num_layers"], dilated=True,
+                   separable=True, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear=cfg["mask_nonlinear"],
+                   causal=cfg["causal"], n_sources=cfg["n_sources"])
+    return m.to(device)
+
+
+def instrumented_step(trainer, mixture, sources):
+    """Run one step with HIP events around every GEMM / depthwise launch; returns per-kernel totals."""
+    from speech_amd import ops
+    rec = {"gemm_nn": [], "gemm_nt": [], "dw_fwd": [], "dw_bwd": []}
+    orig = {k: getattr(ops, k) for k in rec}
+
+    def wrap(name, work):
+        fn = orig[name]
+
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **k)
+            e1.record()
+            rec[name].append((e0, e1, work(*a, **k)))
+        return inner
+
+    ops.gemm_nn = wrap("gemm_nn", lambda M, T, K, batch, *a, **k: 2.0 * M * T * K * batch)
+    ops.gemm_nt = wrap("gemm_nt", lambda M, N, T, batch, *a, **k: 2.0 * M * N * T * batch)
+    ops.dw_fwd = wrap("dw_fwd", lambda x, w, bias, y, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
+    ops.dw_bwd = wrap("dw_bwd", lambda dn2, x, *a, **k: 4.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
+    try:
+        trainer.step(mixture, sources)
+        torch.cuda.synchronize()
+    finally:
+        for k, f in orig.items():
+            setattr(ops, k, f)
+    out = {}
+    for name, lst in rec.items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in lst)
+        out[name] = dict(launches=len(lst), ms=ms, work=sum(w for _, _, w in lst))
+    return out
+
+
+def cpu_baseline(cfg, steps=3, batch=2):
+    """The oracle's training step (same arithmetic as the reference's loop) on the host CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import convtasnet_oracle as O
+    from speech_amd.utils import synth
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = synth.fill_parameters(O.make_state(cfg), salt=1)
+    opt = O.AdamState(sd)
+    times = []
+    for s in range(steps + 1):
+        mixture, sources = synth.make_batch(batch, cfg["n_sources"], T_SAMPLES, seed=2000 + s)
+        t0 = time.perf_counter()
+        O.train_step(mixture, sources, sd, cfg, opt)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps       # first step is warm-up
+    return dict(value=round(batch / dt, 3), unit="utt/s", cores=cores, kind="port",
+                sample="{} training steps of batch {} (paper config, 4 s @ 8 kHz) after 1 warm-up, "
+                       "PyTorch CPU restatement of the reference step".format(steps, batch))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    from speech_amd.trainer import FlatTrainer
+    from speech_amd.utils import synth
+
+    cfg = PAPER
+    model = build_model(cfg, device)
+    trainer = FlatTrainer(model, PIT1d(NegSISDR(), cfg["n_sources"]), lr=1e-3, max_norm=5.0)
+    n_batches = 4
+    batches = []
+    for i in range(n_batches):
+        mixture, sources = synth.make_batch(args.batch, cfg["n_sources"], T_SAMPLES, seed=1000 * rank + i)
+        batches.append((mixture.to(device), sources.to(device)))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for i in range(args.warmup):
+        loss, _ = trainer.step(*batches[i % n_batches])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = trainer.step(*batches[i % n_batches])
+        losses.append(loss)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    final_loss = float(losses[-1].item()) if losses else float("nan")
+
+    roof = roof_hbm = None
+    extra = {}
+    if rank == 0 and not args.no_roofline:
+        prof = instrumented_step(trainer, *batches[0])
+        gn = prof["gemm_nn"]
+        gt = prof["gemm_nt"]
+        a = gn["work"] / (gn["ms"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="gemm_nn_kernel (f32 MFMA 32x32x2, pointwise conv fwd + dgrad)",
+                    achieved=round(a, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(a / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=gn["launches"],
+                    avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1))
+        b = gt["work"] / (gt["ms"] * 1e-3) / 1e12
+        extra["roofline_wgrad"] = dict(bound="mfma", kernel="gemm_nt_kernel (weight gradients)", achieved=round(b, 2),
+                                       peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                       frac=round(b / PEAK_F32_MFMA_TFLOPS, 4), launches_per_step=gt["launches"],
+                                       avg_launch_us=round(gt["ms"] * 1e3 / gt["launches"], 1))
+        hb = []
+        for name in ("dw_fwd", "dw_bwd"):
+            d = prof[name]
+            gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
+            hb.append(dict(bound="hbm", kernel=name + "_kernel", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
+                           unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None,
+                           launches_per_step=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 1)))
+        roof_hbm = hb
+        step_ms = dt / args.steps * 1e3
+        extra["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+        extra["kernel_ms_per_step"]["step"] = round(step_ms, 3)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg)
+        utts = args.batch * world * args.steps
+        line = {
+            "metric": "Conv-TasNet train utt/s (4 s, 8 kHz, 2-spk)",
+            "value": round(utts / dt, 3),
+            "unit": "utt/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Conv-TasNet paper config N512 L16 B128 H512 Sc128 P3 X8 R3 gLN, 2 speakers, "
+                                   "32000-sample (4 s @ 8 kHz) mixtures, full training step "
+                                   "(fwd + PIT SI-SDR + bwd + all-reduce + clip 5 + Adam 1e-3)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": "dp{}".format(world), "final_loss": round(final_loss, 4)},
+            "roofline": roof,
+            "roofline_hbm": roof_hbm,
+            "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,11 @@ Loading fails loudly: there is no CPU or PyTorch fallback behind these calls.
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7.  Importing torch first makes the dynamic loader resolve
+# this library's dependency to that same runtime instance, so stream handles taken from torch are valid
+# here; loading libctn_hip.so first would bring in a second, separate HIP runtime.
+import torch  # noqa: F401  (must precede CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libctn_hip.so")
 

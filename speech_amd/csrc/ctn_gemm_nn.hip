@@ -197,84 +197,171 @@ __global__ __launch_bounds__(NTH) void gemm_nn_kernel(const ctn_gemm_nn_args a, 
     }
 
     // ------------------------------------------------------------------ epilogue
+    // Accumulator register r of tile (i, j) is output row m(i, r), frame t(j).  Every mode first gathers what it
+    // needs from memory for 16 rows at once (16 independent loads in flight), then computes and stores, so no
+    // load ever waits behind a store.
     const int emode = a.emode;
     const float ea = a.ealpha ? a.ealpha[0] : 1.f;
     float s1 = 0.f, s2 = 0.f;
+    float cs1[TN], cs2[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int t = t_blk + wn0 + j * 32 + l31;
-        const bool tv = t < T;
-        float em = 0.f, er = 1.f;
-        if (emode == CTN_EPI_NORMBWD && tv) {
-            const int64_t i = (int64_t)b * a.essb + (int64_t)t * a.esst;
-            em = a.emean[i];
-            er = a.erstd[i];
-        }
-        float cs1 = 0.f, cs2 = 0.f;
+    for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
+    const int m_w = m_blk + wm0 + 4 * half;
+    const int t_w = t_blk + wn0 + l31;
+
+    auto rowm = [&](int i, int r) { return m_w + i * 32 + (r & 3) + 8 * (r >> 2); };
+
+    if (emode == CTN_EPI_HEADS) {
+        const int Mo = a.Mo;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float bs[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m_blk + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < M && tv) {
-                    float v = acc[i][j][r];
-                    if (emode == CTN_EPI_HEADS) {
-                        if (m < a.Mo) {
-                            v += a.bias ? a.bias[m] : 0.f;
-                            if (a.R) v += a.R[(int64_t)b * a.rbs + (int64_t)m * a.ldr + t];
-                            a.Y[(int64_t)b * a.ybs + (int64_t)m * a.ldy + t] = v;
-                        } else {
-                            const int m2 = m - a.Mo;
-                            v += a.bias2 ? a.bias2[m2] : 0.f;
-                            float* p = a.Y2 + (int64_t)b * a.y2bs + (int64_t)m2 * a.ldy2 + t;
-                            if (a.accumulate) v += *p;
-                            *p = v;
+                const int m = rowm(i, r);
+                float v = 0.f;
+                if (m < M) {
+                    if (m < Mo) {
+                        if (a.bias) v = a.bias[m];
+                    } else if (a.bias2) {
+                        v = a.bias2[m - Mo];
+                    }
+                }
+                bs[r] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int t = t_w + j * 32;
+                const bool tv = t < T;
+                float in[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rowm(i, r);
+                    float v = 0.f;
+                    if (m < M && tv) {
+                        if (m < Mo) {
+                            if (a.R) v = a.R[(int64_t)b * a.rbs + (int64_t)m * a.ldr + t];
+                        } else if (a.accumulate) {
+                            v = a.Y2[(int64_t)b * a.y2bs + (int64_t)(m - Mo) * a.ldy2 + t];
                         }
-                    } else {
-                        float* yp = a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t;
-                        if (emode == CTN_EPI_PRELUBWD) {
-                            const float e = a.E[(int64_t)b * a.ebs + (int64_t)m * a.lde + t];
-                            if (!(e > 0.f)) {
-                                s1 += v * e;
-                                v *= ea;
-                            }
-                            *yp = v;
-                        } else if (emode == CTN_EPI_NORMBWD) {
-                            *yp = v;
-                            const float e = a.E[(int64_t)b * a.ebs + (int64_t)m * a.lde + t];
-                            const float xh = (ctn_prelu(e, ea) - em) * er;
-                            const float g = a.egamma[m] * v;
-                            cs1 += g;
-                            cs2 += g * xh;
-                        } else {
-                            v += a.bias ? a.bias[m] : 0.f;
-                            if (emode == CTN_EPI_SIGMOID) {
-                                v = 1.f / (1.f + expf(-v));
-                            } else if (emode == CTN_EPI_ADD) {
-                                if (a.R) v += a.R[(int64_t)b * a.rbs + (int64_t)m * a.ldr + t];
-                            }
-                            *yp = v;
-                            if (emode == CTN_EPI_STATS) {
-                                const float u = ctn_prelu(v, ea);
-                                cs1 += u;
-                                cs2 += u * u;
-                            }
+                    }
+                    in[r] = v;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rowm(i, r);
+                    if (m < M && tv) {
+                        const float v = acc[i][j][r] + bs[r] + in[r];
+                        if (m < Mo)
+                            a.Y[(int64_t)b * a.ybs + (int64_t)m * a.ldy + t] = v;
+                        else
+                            a.Y2[(int64_t)b * a.y2bs + (int64_t)(m - Mo) * a.ldy2 + t] = v;
+                    }
+                }
+            }
+        }
+    } else if (emode == CTN_EPI_PRELUBWD || emode == CTN_EPI_NORMBWD) {
+        const bool nb = emode == CTN_EPI_NORMBWD;
+        float em[TN], er[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int t = t_w + j * 32;
+            em[j] = 0.f;
+            er[j] = 1.f;
+            if (nb && t < T) {
+                const int64_t si = (int64_t)b * a.essb + (int64_t)t * a.esst;
+                em[j] = a.emean[si];
+                er[j] = a.erstd[si];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float gm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rowm(i, r);
+                gm[r] = (nb && m < M) ? a.egamma[m] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int t = t_w + j * 32;
+                const bool tv = t < T;
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rowm(i, r);
+                    e[r] = (m < M && tv) ? a.E[(int64_t)b * a.ebs + (int64_t)m * a.lde + t] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rowm(i, r);
+                    if (m < M && tv) {
+                        float v = acc[i][j][r];
+                        if (nb) {
+                            const float xh = (ctn_prelu(e[r], ea) - em[j]) * er[j];
+                            const float g = gm[r] * v;
+                            cs1[j] += g;
+                            cs2[j] += g * xh;
+                        } else if (!(e[r] > 0.f)) {
+                            s1 += v * e[r];
+                            v *= ea;
+                        }
+                        a.Y[(int64_t)b * a.ybs + (int64_t)m * a.ldy + t] = v;
+                    }
+                }
+            }
+        }
+    } else {   // STORE, STATS, SIGMOID, ADD
+        const bool has_r = (emode == CTN_EPI_ADD) && a.R != nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float bs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rowm(i, r);
+                bs[r] = (a.bias && m < M) ? a.bias[m] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int t = t_w + j * 32;
+                const bool tv = t < T;
+                float in[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rowm(i, r);
+                    in[r] = (has_r && m < M && tv) ? a.R[(int64_t)b * a.rbs + (int64_t)m * a.ldr + t] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rowm(i, r);
+                    if (m < M && tv) {
+                        float v = acc[i][j][r] + bs[r] + in[r];
+                        if (emode == CTN_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
+                        a.Y[(int64_t)b * a.ybs + (int64_t)m * a.ldy + t] = v;
+                        if (emode == CTN_EPI_STATS) {
+                            const float u = ctn_prelu(v, ea);
+                            cs1[j] += u;
+                            cs2[j] += u * u;
                         }
                     }
                 }
             }
         }
-        if (emode == CTN_EPI_STATS || emode == CTN_EPI_NORMBWD) {
+    }
+    if (emode == CTN_EPI_STATS || emode == CTN_EPI_NORMBWD) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
             if (a.ecol) {   // per-frame sums over this wave's rows; fold the two half-waves first
-                cs1 += __shfl_xor(cs1, 32);
-                cs2 += __shfl_xor(cs2, 32);
-                if (half == 0 && tv) {
-                    atomicAdd(a.ecol + (int64_t)b * a.ecol_bs + t, cs1);
-                    atomicAdd(a.ecol + (int64_t)b * a.ecol_bs + a.ecol_ld + t, cs2);
+                const int t = t_w + j * 32;
+                const float c1 = cs1[j] + __shfl_xor(cs1[j], 32);
+                const float c2 = cs2[j] + __shfl_xor(cs2[j], 32);
+                if (half == 0 && t < T) {
+                    atomicAdd(a.ecol + (int64_t)b * a.ecol_bs + t, c1);
+                    atomicAdd(a.ecol + (int64_t)b * a.ecol_bs + a.ecol_ld + t, c2);
                 }
             } else {
-                s1 += cs1;
-                s2 += cs2;
+                s1 += cs1[j];
+                s2 += cs2[j];
             }
         }
     }
@@ -289,6 +376,333 @@ __global__ __launch_bounds__(NTH) void gemm_nn_kernel(const ctn_gemm_nn_args a, 
             atomicAdd(a.esums + (int64_t)b * 2 + tid, (double)tot);
         }
     }
+}
+
+// ================================================================================================
+// Fast path for 16-byte-aligned operands and M % 4 == 0 (every paper-config shape).
+//
+// 128 x 128 output tile, BK = 16, 4 waves of 64 x 64.  Operand tiles go global -> LDS directly
+// (global_load_lds_dwordx4, no staging registers) into two buffers, so the loads of k-tile kt+1 are in
+// flight while the MFMAs of k-tile kt run, with one barrier per k-tile.  The operand transform is applied
+// to the B fragment right after its ds_read (per-frame statistics live in registers, per-channel
+// gamma/beta in LDS), so it rides in the VALU slots between MFMAs.  The accumulators leave through LDS:
+// each thread then handles float4s of whole rows, which makes every epilogue load/store a coalesced
+// 16-byte access and keeps register use low enough for several resident blocks per CU.
+// ================================================================================================
+constexpr int FBM = 128, FBN = 128, FBK = 16;
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+#define CTN_GLDS16(gp, lp)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp),        \
+                                     (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+template <bool BWD>
+__global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
+                                                           const int tiles_n) {
+    // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TILE_A = FBK * FBM, TILE_X = FBK * FBN;
+    constexpr int BUF = TILE_A + TILE_X + (BWD ? TILE_X : 0);
+    __shared__ float red[2 * (NTH / 64)];
+
+    const int total = gridDim.x, hb = blockIdx.x;
+    const int q8 = total >> 3, rr = total & 7, xcd = hb & 7;
+    const int lb = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (hb >> 3);
+    const int tile_m = lb % tiles_m;
+    const int rest = lb / tiles_m;
+    const int tile_n = rest % tiles_n;
+    const int b = rest / tiles_n;
+    const int m_blk = tile_m * FBM, t_blk = tile_n * FBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int M = a.M, T = a.T, K = a.K, K1 = a.K1;
+    const int xflags = a.xflags;
+    const float alpha = a.alpha ? a.alpha[0] : 1.f;
+    const int nk = (K + FBK - 1) / FBK;
+    const int Kp = nk * FBK;
+    float* Gs = lds + 2 * BUF;
+    float* Bes = Gs + Kp;
+    const bool has_norm = (xflags & (CTN_XF_NORM | CTN_XF_NORMBWD)) != 0;
+    if (has_norm) {
+        for (int k = tid; k < Kp; k += NTH) {
+            Gs[k] = k < K ? a.gamma[k] : 0.f;
+            Bes[k] = (!BWD && k < K) ? a.beta[k] : 0.f;
+        }
+    }
+    // per-frame statistics of this lane's two columns
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f}, c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
+    if (has_norm) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = min(t_blk + wn0 + j * 32 + l31, T - 1);
+            const int64_t si = (int64_t)b * a.ssb + (int64_t)t * a.sst;
+            mean[j] = a.mean[si];
+            rstd[j] = a.rstd[si];
+            if (BWD) {
+                c1[j] = a.c1[si];
+                c2[j] = a.c2[si];
+            }
+        }
+    }
+
+    // each wave issues 1 KiB pieces: piece p covers tile rows 2p, 2p+1 (32 lanes x 16 B per row)
+    const int prow = lane >> 5, pcol = (lane & 31) * 4;
+    auto issue = [&](int kt, int buf) {
+        float* base = lds + buf * BUF;
+        const int k0 = kt * FBK;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                 // A tile: 8 pieces, 2 per wave
+            const int p = wave * 2 + pp;
+            const int k = k0 + 2 * p + prow, m = m_blk + pcol;
+            const float* src = g_zero16;
+            if (k < K && m < M) src = (k < K1) ? a.A + (int64_t)k * a.lda + m : a.A2 + (int64_t)(k - K1) * a.lda2 + m;
+            CTN_GLDS16(src, base + p * 256);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                 // X tile
+            const int p = wave * 2 + pp;
+            const int k = k0 + 2 * p + prow, t = t_blk + pcol;
+            const float* src = g_zero16;
+            if (k < K) {
+                if (k < K1) {
+                    if (t < a.ldx) src = a.X + (int64_t)b * a.xbs + (int64_t)k * a.ldx + t;
+                } else if (t < a.ldxb) {
+                    src = a.Xb + (int64_t)b * a.xbbs + (int64_t)(k - K1) * a.ldxb + t;
+                }
+            }
+            CTN_GLDS16(src, base + TILE_A + p * 256);
+        }
+        if (BWD) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int p = wave * 2 + pp;
+                const int k = k0 + 2 * p + prow, t = t_blk + pcol;
+                const float* src = g_zero16;
+                if (k < K && t < a.ldx2) src = a.X2 + (int64_t)b * a.x2bs + (int64_t)k * a.ldx2 + t;
+                CTN_GLDS16(src, base + TILE_A + TILE_X + p * 256);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();          // tile kt has landed (vmcnt drained before the barrier); buffer (kt+1)&1 is free
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const float* As = lds + (kt & 1) * BUF;
+        const float* Xs = As + TILE_A;
+        const float* X2s = Xs + TILE_X;
+        const int k0 = kt * FBK;
+#pragma unroll
+        for (int kk = 0; kk < FBK / 2; ++kk) {
+            const int k = 2 * kk + half;
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = As[k * FBM + wm0 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Xs[k * FBN + wn0 + j * 32 + l31];
+            if (BWD) {
+                const float g = Gs[k0 + k];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float y = X2s[k * FBN + wn0 + j * 32 + l31];
+                    const float u = ctn_prelu(y, alpha);
+                    const float du = g * bv[j] * rstd[j] + c1[j] + (u - mean[j]) * c2[j];
+                    bv[j] = y > 0.f ? du : alpha * du;
+                }
+            } else {
+                if (xflags & CTN_XF_PRELU) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bv[j] = ctn_prelu(bv[j], alpha);
+                }
+                if (xflags & CTN_XF_NORM) {
+                    const float g = Gs[k0 + k], be = Bes[k0 + k];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bv[j] = (bv[j] - mean[j]) * rstd[j] * g + be;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();              // every wave is done with the tiles: reuse them as epilogue staging
+
+    // ------------------------------------------------------------------ epilogue through LDS
+    float* stg = lds;             // 64 x 128 floats = 32 KiB <= 2 * BUF
+    const int emode = a.emode;
+    const float ea = a.ealpha ? a.ealpha[0] : 1.f;
+    const int c4 = (tid & 31) * 4, r0 = tid >> 5;          // this thread: columns c4..c4+3, rows r0 + 8q
+    const int t = t_blk + c4;
+    const bool col_ok = t < a.ldy;                          // the float4 lies inside the row
+    float em[4] = {0, 0, 0, 0}, er[4] = {1, 1, 1, 1};
+    if (emode == CTN_EPI_NORMBWD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t si = (int64_t)b * a.essb + (int64_t)min(t + e, T - 1) * a.esst;
+            em[e] = a.emean[si];
+            er[e] = a.erstd[si];
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+    float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
+    const bool want_stats = (emode == CTN_EPI_STATS || emode == CTN_EPI_NORMBWD);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((wave >> 1) == pass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN + wn0 + j * 32 + l31] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (col_ok) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = r0 + 8 * q;
+                const int m = m_blk + pass * 64 + row;
+                if (m >= M) continue;
+                f32x4 v = ctn_ld4(&stg[row * FBN + c4]);
+                if (emode == CTN_EPI_HEADS) {
+                    if (m < a.Mo) {
+                        const float bsv = a.bias ? a.bias[m] : 0.f;
+                        if (a.R) {
+                            const f32x4 rv = ctn_ld4(a.R + (int64_t)b * a.rbs + (int64_t)m * a.ldr + t);
+                            v += rv;
+                        }
+                        v += bsv;
+                        ctn_st4(a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t, v);
+                    } else {
+                        const int m2 = m - a.Mo;
+                        const float bsv = a.bias2 ? a.bias2[m2] : 0.f;
+                        float* p = a.Y2 + (int64_t)b * a.y2bs + (int64_t)m2 * a.ldy2 + t;
+                        if (a.accumulate) v += ctn_ld4(p);
+                        v += bsv;
+                        ctn_st4(p, v);
+                    }
+                } else if (emode == CTN_EPI_PRELUBWD || emode == CTN_EPI_NORMBWD) {
+                    const f32x4 ev = ctn_ld4(a.E + (int64_t)b * a.ebs + (int64_t)m * a.lde + t);
+                    if (emode == CTN_EPI_NORMBWD) {
+                        const float gmv = a.egamma[m];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (t + e < T) {
+                                const float xh = (ctn_prelu(ev[e], ea) - em[e]) * er[e];
+                                const float g = gmv * v[e];
+                                cs1[e] += g;
+                                cs2[e] += g * xh;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (!(ev[e] > 0.f)) {
+                                if (t + e < T) s1 += v[e] * ev[e];
+                                v[e] *= ea;
+                            }
+                        }
+                    }
+                    ctn_st4(a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t, v);
+                } else {
+                    v += a.bias ? a.bias[m] : 0.f;
+                    if (emode == CTN_EPI_ADD && a.R) v += ctn_ld4(a.R + (int64_t)b * a.rbs + (int64_t)m * a.ldr + t);
+                    if (emode == CTN_EPI_SIGMOID) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + expf(-v[e]));
+                    }
+                    ctn_st4(a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t, v);
+                    if (emode == CTN_EPI_STATS) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (t + e < T) {
+                                const float u = ctn_prelu(v[e], ea);
+                                cs1[e] += u;
+                                cs2[e] += u * u;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (want_stats) {
+        if (a.ecol) {            // per-frame sums: fold the 8 row groups through LDS, one atomic per frame
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                stg[(r0 * 2 + 0) * FBN + c4 + e] = cs1[e];
+                stg[(r0 * 2 + 1) * FBN + c4 + e] = cs2[e];
+            }
+            __syncthreads();
+            const int col = tid & 127, which = tid >> 7;
+            float tot = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) tot += stg[(g * 2 + which) * FBN + col];
+            const int tc = t_blk + col;
+            if (tc < T) atomicAdd(a.ecol + (int64_t)b * a.ecol_bs + (int64_t)which * a.ecol_ld + tc, tot);
+        } else {
+            s1 = cs1[0] + cs1[1] + cs1[2] + cs1[3];
+            s2 = cs2[0] + cs2[1] + cs2[2] + cs2[3];
+        }
+    }
+    const bool sums = (emode == CTN_EPI_PRELUBWD) || (want_stats && a.esums != nullptr);
+    if (sums) {
+        float v[2] = {s1, s2};
+        const float tot = ctn_block_sum<2>(v, red);
+        if (emode == CTN_EPI_PRELUBWD) {
+            if (tid == 0 && a.esums) atomicAdd(a.esums, (double)tot);
+        } else if (tid < 2) {
+            atomicAdd(a.esums + (int64_t)b * 2 + tid, (double)tot);
+        }
+    }
+}
+
+bool fast_ok(const ctn_gemm_nn_args& a) {
+    auto al = [](const void* p) { return p == nullptr || ctn_aligned16(p); };
+    if (a.M <= 64 || a.M % 4 != 0) return false;
+    if (!ctn_aligned16(a.A) || a.lda % 4 != 0) return false;
+    if (a.K1 < a.K && (!ctn_aligned16(a.A2) || a.lda2 % 4 != 0)) return false;
+    if (!ctn_aligned16(a.Y) || a.ldy % 4 != 0 || a.ybs % 4 != 0) return false;
+    if (a.R && (!al(a.R) || a.ldr % 4 != 0 || a.rbs % 4 != 0 || a.ldr < a.ldy)) return false;
+    if (a.Y2 && (!al(a.Y2) || a.ldy2 % 4 != 0 || a.y2bs % 4 != 0 || a.ldy2 < a.ldy)) return false;
+    if (a.E && (!al(a.E) || a.lde % 4 != 0 || a.ebs % 4 != 0 || a.lde < a.ldy)) return false;
+    if ((int64_t)a.K > 4096) return false;
+    return true;
+}
+
+int launch_fast(const ctn_gemm_nn_args& a, hipStream_t s) {
+    const int tiles_m = ctn_cdiv(a.M, FBM), tiles_n = ctn_cdiv(a.T, FBN);
+    const int64_t total = (int64_t)tiles_m * tiles_n * a.batch;
+    if (total > 0x7fffffff) {
+        ctn_set_error("ctn_gemm_nn: grid too large");
+        return CTN_ERR_ARG;
+    }
+    const int Kp = ctn_cdiv(a.K, FBK) * FBK;
+    const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
+    const size_t buf = (size_t)(FBK * FBM + FBK * FBN + (bwd ? FBK * FBN : 0));
+    size_t floats = 2 * buf + 2 * (size_t)Kp;
+    if (floats < 64 * FBN) floats = 64 * FBN;      // epilogue staging
+    const size_t shmem = floats * sizeof(float);
+    if (bwd)
+        hipLaunchKernelGGL((gemm_nn_fast_kernel<true>), dim3((unsigned)total), dim3(NTH), shmem, s, a, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_nn_fast_kernel<false>), dim3((unsigned)total), dim3(NTH), shmem, s, a, tiles_m,
+                           tiles_n);
+    return CTN_OK;
 }
 
 template <int BM, int WAVES_M>
@@ -357,7 +771,9 @@ extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
                      (a.K1 == a.K || (ctn_aligned16(a.A2) && a.lda2 % 4 == 0));
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (a.M > 64)
+    if (fast_ok(a))
+        rc = launch_fast(a, s);
+    else if (a.M > 64)
         rc = launch<128, 2>(a, vecA, s);
     else if (a.M > 32)
         rc = launch<64, 2>(a, vecA, s);

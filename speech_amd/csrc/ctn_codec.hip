@@ -114,12 +114,11 @@ __global__ __launch_bounds__(NTH) void maskdecode_fwd_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------ shared phase B
 // V[ns][FT rows n_local][LDV] holds values per (channel, frame); F[ns][FT][ML] the matching frames of the
-// time-domain signal.  Thread (n_local, q) accumulates sum_f V[n][f] * F[f][l] over its quarter of the frames.
+// time-domain signal.  Thread (n_local, q) adds sum_f V[n][f] * F[f][l] over its quarter of the frames to acc.
+// corr_flush folds the four quarters through LDS (scratch: 4 x 64 x ML floats) and issues one atomic per (n, l).
 template <int ML, int NS>
 __device__ __forceinline__ void corr_accumulate(const float* V, const float* F, int L, float (&acc)[ML]) {
     const int nl = threadIdx.x & 63, q = threadIdx.x >> 6;
-#pragma unroll
-    for (int l = 0; l < ML; ++l) acc[l] = 0.f;
     for (int s = 0; s < NS; ++s) {
         const float* Vs = V + (size_t)s * FT * LDV + nl * LDV;
         const float* Fs = F + (size_t)s * FT * ML;
@@ -128,6 +127,26 @@ __device__ __forceinline__ void corr_accumulate(const float* V, const float* F, 
 #pragma unroll
             for (int l = 0; l < ML; ++l)
                 if (l < L) acc[l] += h * Fs[fl * ML + l];
+        }
+    }
+}
+
+template <int ML>
+__device__ __forceinline__ void corr_flush(float* scratch, const float (&acc)[ML], int L, int n0, int N, float* dW) {
+    const int nl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < ML; ++l) scratch[(q * 64 + nl) * ML + l] = acc[l];
+    __syncthreads();
+    const int n = n0 + nl;
+    if (q == 0 && n < N) {
+#pragma unroll
+        for (int l = 0; l < ML; ++l) {
+            if (l < L) {
+                const float v = (scratch[nl * ML + l] + scratch[(64 + nl) * ML + l]) +
+                                (scratch[(128 + nl) * ML + l] + scratch[(192 + nl) * ML + l]);
+                atomicAdd(dW + (int64_t)n * L + l, v);
+            }
         }
     }
 }
@@ -142,12 +161,19 @@ __global__ __launch_bounds__(NTH) void maskdecode_bwd_kernel(const float* __rest
                                                              int Tf, const float* __restrict__ Wd, int L, int S,
                                                              int sigmoid_bwd, float* __restrict__ dz,
                                                              int64_t lddz, float* __restrict__ dw_dec,
-                                                             int64_t lddw, float* dWd) {
+                                                             int64_t lddw, float* dWd, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* V = lds;                               // [NS][64][LDV]
+    float* V = lds;                               // [NS][64][LDV]   (>= 4 * 64 * ML floats: also corr_flush scratch)
     float* F = lds + (size_t)NS * FT * LDV;       // [NS][FT][ML]
-    const int b = blockIdx.z, n0 = blockIdx.y * 64, f0 = blockIdx.x * FT;
+    const int b = blockIdx.z, n0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[ML];
+#pragma unroll
+    for (int l = 0; l < ML; ++l) acc[l] = 0.f;
+    const int ntiles = (Tf + FT - 1) / FT;
+    const int tile_end = min((int)(blockIdx.x + 1) * tiles_per_block, ntiles);
+  for (int tile = blockIdx.x * tiles_per_block; tile < tile_end; ++tile) {
+    const int f0 = tile * FT;
     const int f = f0 + lane;
     const bool fv = f < Tf;
     float dx[NS][ML];
@@ -191,14 +217,10 @@ __global__ __launch_bounds__(NTH) void maskdecode_bwd_kernel(const float* __rest
         if (dw_dec && nv && fv) dw_dec[((int64_t)b * N + n) * lddw + f] = dwsum;
     }
     __syncthreads();
-    float acc[ML];
     corr_accumulate<ML, NS>(V, F, L, acc);
-    const int n = n0 + (threadIdx.x & 63);
-    if (n < N) {
-#pragma unroll
-        for (int l = 0; l < ML; ++l)
-            if (l < L) atomicAdd(dWd + (int64_t)n * L + l, acc[l]);
-    }
+    __syncthreads();
+  }
+    corr_flush<ML>(V, acc, L, n0, N, dWd);
 }
 
 // ------------------------------------------------------------------------------------------ encoder bwd
@@ -212,11 +234,21 @@ __global__ __launch_bounds__(NTH) void encoder_bwd_kernel(const float* __restric
                                                           const float* c2, int64_t ssb, int64_t sst,
                                                           const float* __restrict__ gamma, float* dW,
                                                           float* dgamma, float* dbeta, float* dwt_out,
-                                                          int64_t lddwt) {
-    __shared__ float V[FT * LDV];
+                                                          int64_t lddwt, int tiles_per_block) {
+    __shared__ float V[FT * LDV];                 // 64 x 65 >= 4 * 64 * ML floats: also corr_flush scratch
     __shared__ float F[FT * ML];
-    const int b = blockIdx.z, n0 = blockIdx.y * 64, f0 = blockIdx.x * FT;
+    const int b = blockIdx.z, n0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[ML];
+#pragma unroll
+    for (int l = 0; l < ML; ++l) acc[l] = 0.f;
+    float gxa[16], gda[16];                       // per-channel norm-gradient partials of this wave's 16 channels
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gxa[i] = gda[i] = 0.f;
+    const int ntiles = (Tf + FT - 1) / FT;
+    const int tile_end = min((int)(blockIdx.x + 1) * tiles_per_block, ntiles);
+  for (int tile = blockIdx.x * tiles_per_block; tile < tile_end; ++tile) {
+    const int f0 = tile * FT;
     const int f = f0 + lane;
     const bool fv = f < Tf;
     if (wave == 0) {
@@ -231,6 +263,7 @@ __global__ __launch_bounds__(NTH) void encoder_bwd_kernel(const float* __restric
         const int64_t si = (int64_t)b * ssb + (int64_t)f * sst;
         mu = mean[si]; rs = rstd[si]; k1 = c1[si]; k2 = c2[si];
     }
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int nl = wave * 16 + i, n = n0 + nl;
         const bool ok = (n < N) && fv;
@@ -249,24 +282,35 @@ __global__ __launch_bounds__(NTH) void encoder_bwd_kernel(const float* __restric
             if (dwt_out) dwt_out[((int64_t)b * N + n) * lddwt + f] = dwt;
         }
         V[nl * LDV + lane] = dwt;
-        if (dn) {
-            gx = ctn_wave_sum(gx);
-            gd = ctn_wave_sum(gd);
+        gxa[i] += gx;
+        gda[i] += gd;
+    }
+    __syncthreads();
+    corr_accumulate<ML, 1>(V, F, L, acc);
+    __syncthreads();
+  }
+    if (dn) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = n0 + wave * 16 + i;
+            const float gx = ctn_wave_sum(gxa[i]);
+            const float gd = ctn_wave_sum(gda[i]);
             if (lane == 0 && n < N) {
                 atomicAdd(dgamma + n, gx);
                 atomicAdd(dbeta + n, gd);
             }
         }
     }
-    __syncthreads();
-    float acc[ML];
-    corr_accumulate<ML, 1>(V, F, L, acc);
-    const int n = n0 + (threadIdx.x & 63);
-    if (n < N) {
-#pragma unroll
-        for (int l = 0; l < ML; ++l)
-            if (l < L) atomicAdd(dW + (int64_t)n * L + l, acc[l]);
-    }
+    corr_flush<ML>(V, acc, L, n0, N, dW);
+}
+
+// Frame tiles walked by one block of the weight-gradient kernels: enough blocks to fill the chip (~1500),
+// as few as possible beyond that, because every block ends in N*L contended atomics.
+int tiles_per_block(int ntiles, int other_blocks) {
+    int tpb = (int)(((int64_t)ntiles * other_blocks + 1535) / 1536);
+    if (tpb < 1) tpb = 1;
+    if (tpb > ntiles) tpb = ntiles;
+    return tpb;
 }
 
 }  // namespace
@@ -325,13 +369,15 @@ int ctn_maskdecode_bwd(const float* dout, int64_t dout_ss, int64_t dout_bs, int 
     CTN_REQUIRE(ldw >= Tf && (!mask || ldm >= Tf) && (!dz || lddz >= Tf) && (!dw_dec || lddw >= Tf),
                 "ctn_maskdecode_bwd: ld < Tf");
     CTN_REQUIRE(!mask || dz, "ctn_maskdecode_bwd: dz required with a mask");
-    dim3 grid(ctn_cdiv(Tf, FT), ctn_cdiv(N, 64), batch);
+    const int ntiles = ctn_cdiv(Tf, FT);
+    const int tpb = tiles_per_block(ntiles, ctn_cdiv(N, 64) * batch);
+    dim3 grid(ctn_cdiv(ntiles, tpb), ctn_cdiv(N, 64), batch);
     hipStream_t s = (hipStream_t)stream;
     const size_t shmem = ((size_t)n_src * FT * LDV + (size_t)n_src * FT * 16) * sizeof(float);
 #define CTN_MD_CASE(NS)                                                                                         \
     case NS:                                                                                                    \
         hipLaunchKernelGGL((maskdecode_bwd_kernel<16, NS>), grid, dim3(NTH), shmem, s, dout, dout_ss, dout_bs, Tout, \
-                           trim_left, w, ldw, mask, ldm, N, Tf, Wd, L, S, sigmoid_bwd, dz, lddz, dw_dec, lddw, dWd);  \
+                           trim_left, w, ldw, mask, ldm, N, Tf, Wd, L, S, sigmoid_bwd, dz, lddz, dw_dec, lddw, dWd, tpb);  \
         break;
     switch (n_src) { CTN_MD_CASE(1) CTN_MD_CASE(2) CTN_MD_CASE(3) }
 #undef CTN_MD_CASE
@@ -350,10 +396,12 @@ int ctn_encoder_bwd(const float* x, int64_t xbs, int Tin, int pad_left, int batc
                 "ctn_encoder_bwd: ld < Tf");
     CTN_REQUIRE(dw_a || dn, "ctn_encoder_bwd: no incoming gradient");
     if (dn) CTN_REQUIRE(mean && rstd && c1 && c2 && gamma && dgamma && dbeta, "ctn_encoder_bwd: norm arguments");
-    dim3 grid(ctn_cdiv(Tf, FT), ctn_cdiv(N, 64), batch);
+    const int ntiles = ctn_cdiv(Tf, FT);
+    const int tpb = tiles_per_block(ntiles, ctn_cdiv(N, 64) * batch);
+    dim3 grid(ctn_cdiv(ntiles, tpb), ctn_cdiv(N, 64), batch);
     hipLaunchKernelGGL(encoder_bwd_kernel<16>, grid, dim3(NTH), 0, (hipStream_t)stream, x, xbs, Tin, pad_left, N, L,
                        S, relu, w, Tf, ldw, dw_a, lddwa, dn, lddn, mean, rstd, c1, c2, ssb, sst, gamma, dW, dgamma,
-                       dbeta, dwt_out, lddwt);
+                       dbeta, dwt_out, lddwt, tpb);
     CTN_CHECK_LAUNCH("ctn_encoder_bwd");
     return CTN_OK;
 }

@@ -312,6 +312,7 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, relu):
+        ops._require_cuda(x, weight)
         B, C_in, T = x.shape
         if C_in != 1:
             raise NotImplementedError("HIP encoder supports in_channels == 1")
@@ -455,6 +456,7 @@ class ConvTasNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
+        ops._require_cuda(x, params[0])
         mp = ModelParams(params, cfg)
         B, C_in, T = x.shape
         L, S = cfg["kernel_size"], cfg["stride"]

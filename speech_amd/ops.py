@@ -20,6 +20,8 @@ def _ptr(t):
 
 
 def _stream():
+    if not torch.cuda.is_available():
+        raise _lib.CtnError("speech_amd operators need an MI355X (no GPU visible); there is no CPU path")
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -15,6 +15,31 @@ from . import ops
 from .functional import ConvTasNetFn
 
 
+def allreduce_flat(flat, n_buckets=1, group=None):
+    """Sum-all-reduce a flat gradient buffer in `n_buckets` contiguous chunks (asynchronously, then wait).
+    The result is independent of n_buckets; with the NCCL backend this is RCCL over xGMI."""
+    n = flat.numel()
+    n_buckets = max(1, min(n_buckets, n))
+    per = (n + n_buckets - 1) // n_buckets
+    works = []
+    for i in range(n_buckets):
+        chunk = flat[i * per:min((i + 1) * per, n)]
+        if chunk.numel():
+            works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return flat
+
+
+def shard_batch(mixture, sources, rank, world):
+    """Equal contiguous shard of a global batch for `rank` (the batch must divide evenly)."""
+    B = mixture.shape[0]
+    if B % world:
+        raise ValueError("global batch {} does not divide over {} ranks".format(B, world))
+    per = B // world
+    return mixture[rank * per:(rank + 1) * per], sources[rank * per:(rank + 1) * per]
+
+
 class FlatTrainer:
     def __init__(self, model, criterion, lr=1e-3, max_norm=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None,
                  n_buckets=1):
@@ -64,15 +89,7 @@ class FlatTrainer:
     def reduce_gradients(self):
         if self.world == 1:
             return
-        n = self.flat_g.numel()
-        per = (n + self.n_buckets - 1) // self.n_buckets
-        works = []
-        for i in range(self.n_buckets):
-            chunk = self.flat_g[i * per:min((i + 1) * per, n)]
-            if chunk.numel():
-                works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
+        allreduce_flat(self.flat_g, self.n_buckets, self.group)
 
     def optimizer_step(self):
         self.step_count += 1

@@ -39,6 +39,12 @@
 extern "C" {
 #endif
 
+/* Scalar fp64 accumulators are replicated CTN_STAT_SLOTS ways to avoid same-address atomic contention:
+ *   norm sums   double[batch][CTN_STAT_SLOTS][2]   (every `sums` / `esums` / `isums` argument below)
+ *   dalpha      double[CTN_STAT_SLOTS]             (every PReLU-slope gradient accumulator)
+ * The value is the sum over the slot axis; ctn_gln_finalize / ctn_gln_bwd_coefs do that sum themselves. */
+#define CTN_STAT_SLOTS 32
+
 #define CTN_OK 0
 #define CTN_ERR_ARG (-1)     /* bad shape / alignment / null pointer */
 #define CTN_ERR_LAUNCH (-2)  /* hipLaunchKernel reported an error */
@@ -101,7 +107,7 @@ typedef struct {
     int32_t accumulate;               /* HEADS: Y2 += instead of = */
     int32_t pad0;
     const float* ealpha;              /* STATS / PRELUBWD / NORMBWD slope (NULL = 1, i.e. no PReLU) */
-    double* esums;                    /* [batch][2] (+=), PRELUBWD: [1] */
+    double* esums;                    /* [batch][CTN_STAT_SLOTS][2] (+=), PRELUBWD: [CTN_STAT_SLOTS] */
     float* ecol; int64_t ecol_bs, ecol_ld;   /* cLN: [batch][2][ecol_ld] column sums (+=) */
     const float* E; int64_t lde, ebs; /* epilogue input (batch, M, lde) */
     const float* emean; const float* erstd; int64_t essb, esst;
@@ -129,7 +135,7 @@ typedef struct {
     const float* a_gamma;
     float* a_rowsum;  /* [M1]     += sum_t A'[m][t]      (NULL to skip) */
     float* a_rowsum2; /* [M - M1] */
-    double* a_dalpha; /* NORMBWD: += sum du * min(y, 0)  (NULL to skip) */
+    double* a_dalpha; /* NORMBWD: [CTN_STAT_SLOTS] += sum du * min(y, 0)  (NULL to skip) */
     const float* B; int64_t ldb, bbs;
     int32_t bflags;                           /* CTN_XF_PRELU | CTN_XF_NORM */
     int32_t kchunk;                           /* time steps per block, multiple of 32 */
@@ -199,7 +205,7 @@ typedef struct {
     const float* bias;                /* [C] or NULL */
     float* y; int64_t ldy, ybs;
     const float* alpha_out;           /* statistics of prelu(y, alpha_out); NULL: no statistics */
-    double* esums;                    /* [batch][2] += */
+    double* esums;                    /* [batch][CTN_STAT_SLOTS][2] += */
     float* ecol; int64_t ecol_ld;     /* [batch][2][ecol_ld] += */
 } ctn_dw_fwd_args;
 

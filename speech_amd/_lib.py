@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libctn_hip.so")
 
 XF_PRELU, XF_NORM, XF_NORMBWD = 1, 2, 4
+STAT_SLOTS = 32          # CTN_STAT_SLOTS of include/ctn.h
 EPI_STORE, EPI_STATS, EPI_HEADS, EPI_SIGMOID, EPI_PRELUBWD, EPI_NORMBWD, EPI_ADD = range(7)
 
 _p = C.c_void_p

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NTH) void encoder_fwd_kernel(const float* __restric
     } else if (sums) {
         float v[2] = {s1, s2};
         const float tot = ctn_block_sum<2>(v, red);
-        if (threadIdx.x < 2) atomicAdd(sums + (int64_t)b * 2 + threadIdx.x, (double)tot);
+        if (threadIdx.x < 2) atomicAdd(sums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + threadIdx.x, (double)tot);
     }
 }
 

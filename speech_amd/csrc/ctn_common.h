@@ -33,6 +33,13 @@ static inline int ctn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 
 #define CTN_WAVE 64
 
+// Scalar fp64 accumulators (norm sums, PReLU-slope gradients) are CTN_STAT_SLOTS-way replicated: thousands of
+// blocks adding to ONE address serialise at the memory side, so each block adds to the slot picked by its
+// block index and the (tiny) consumer kernels / the host sum the slots.
+__device__ __forceinline__ int ctn_slot() {
+    return (int)((blockIdx.x + 5u * blockIdx.y + 11u * blockIdx.z) & (CTN_STAT_SLOTS - 1));
+}
+
 __device__ __forceinline__ float ctn_prelu(float v, float a) { return v > 0.f ? v : a * v; }
 
 __device__ __forceinline__ float ctn_wave_sum(float v) {

@@ -16,6 +16,33 @@ constexpr int MAXP = 8;
 
 __device__ __forceinline__ int floor4(int v) { return v & ~3; }
 
+// 4 consecutive floats starting at row[off] (off >= 0, row 16-byte aligned): one ds_read_b128 when off % 4 == 0
+// (every layer with dilation % 4 == 0), scalar reads otherwise.  off % 4 is the same in every lane.
+__device__ __forceinline__ f32x4 lds_read4(const float* row, int off) {
+    f32x4 r;
+    if ((off & 3) == 0) {
+        r = ctn_ld4(row + off);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = row[off + e];
+    }
+    return r;
+}
+
+// Per-frame statistics of 4 consecutive frames; gLN (st == 0) was hoisted to scalars by the caller.
+__device__ __forceinline__ void stat4(const float* p, int64_t sb, int64_t st, int b, int t, int T, float hoisted,
+                                      float (&o)[4]) {
+    if (st == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hoisted;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = p[(int64_t)b * sb + (int64_t)min(t + e, T - 1) * st];
+    }
+}
+
+constexpr int NIT = 5;   // float4s staged per thread and round: 5 * 256 * 4 = 5120 frames covers T' = 3999 + halo
+
 // ------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, const int CG, const int TT,
                                                      const int lw) {
@@ -28,34 +55,56 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
     const float ain = a.alpha_in ? a.alpha_in[0] : 1.f;
     const float aout = a.alpha_out ? a.alpha_out[0] : 1.f;
     const bool do_stats = a.alpha_out != nullptr || a.esums != nullptr || a.ecol != nullptr;
+    const bool norm = (a.xflags & CTN_XF_NORM) != 0;
+    const bool prelu_in = (a.xflags & CTN_XF_PRELU) != 0;
     const int cend = min(c0 + CG, a.C);
     const int t_end = min(t0 + TT, T);
+    const int lw4 = lw / 4;
+    float mean0 = 0.f, rstd0 = 1.f;
+    if (norm && a.sst == 0) {
+        mean0 = a.mean[(int64_t)b * a.ssb];
+        rstd0 = a.rstd[(int64_t)b * a.ssb];
+    }
 
     float s1 = 0.f, s2 = 0.f;                 // gLN partial sums
     float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};   // cLN per-frame sums (one float4 per thread)
 
     for (int c = c0; c < cend; ++c) {
-        // ---- stage the transformed, zero-padded input row
+        // ---- stage the transformed, zero-padded input row: all loads of a round are issued before any is used
         const float* xrow = a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx;
-        const float g = (a.xflags & CTN_XF_NORM) ? a.gamma[c] : 1.f;
-        const float be = (a.xflags & CTN_XF_NORM) ? a.beta[c] : 0.f;
-        for (int i4 = tid; i4 < lw / 4; i4 += NTH) {
-            const int t = tA + 4 * i4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < T) {
-                v = ctn_ld4(xrow + t);
+        const float g = norm ? a.gamma[c] : 1.f;
+        const float be = norm ? a.beta[c] : 0.f;
+        for (int r0 = 0; r0 < lw4; r0 += NIT * NTH) {
+            f32x4 v[NIT];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float u = v[e];
-                    if (a.xflags & CTN_XF_PRELU) u = ctn_prelu(u, ain);
-                    if (a.xflags & CTN_XF_NORM) {
-                        const int64_t si = (int64_t)b * a.ssb + (int64_t)min(t + e, T - 1) * a.sst;
-                        u = (u - a.mean[si]) * a.rstd[si] * g + be;
-                    }
-                    v[e] = (t + e < T) ? u : 0.f;
-                }
+            for (int j = 0; j < NIT; ++j) {
+                const int i4 = r0 + tid + j * NTH;
+                const int t = tA + 4 * i4;
+                v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i4 < lw4 && t >= 0 && t < T) v[j] = ctn_ld4(xrow + t);
             }
-            ctn_st4(&lds[4 * i4], v);
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int i4 = r0 + tid + j * NTH;
+                const int t = tA + 4 * i4;
+                if (i4 >= lw4) continue;
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (t >= 0 && t < T) {
+                    float mu[4], rs[4];
+                    if (norm) {
+                        stat4(a.mean, a.ssb, a.sst, b, t, T, mean0, mu);
+                        stat4(a.rstd, a.ssb, a.sst, b, t, T, rstd0, rs);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = v[j][e];
+                        if (prelu_in) u = ctn_prelu(u, ain);
+                        if (norm) u = (u - mu[e]) * rs[e] * g + be;
+                        o[e] = (t + e < T) ? u : 0.f;
+                    }
+                }
+                ctn_st4(&lds[4 * i4], o);
+            }
         }
         __syncthreads();
         // ---- taps
@@ -66,14 +115,13 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
         float* yrow = a.y + (int64_t)b * a.ybs + (int64_t)c * a.ldy;
         for (int t = t0 + 4 * tid; t < t_end; t += 4 * NTH) {
             const int base = t - padL - tA;
-            f32x4 o;
+            f32x4 o = {bias, bias, bias, bias};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float acc = bias;
-#pragma unroll
-                for (int k = 0; k < MAXP; ++k)
-                    if (k < P) acc += w[k] * lds[base + e + k * d];
-                o[e] = acc;
+            for (int k = 0; k < MAXP; ++k) {
+                if (k < P) {
+                    const f32x4 x4 = lds_read4(lds, base + k * d);
+                    o += w[k] * x4;
+                }
             }
             ctn_st4(yrow + t, o);
             if (do_stats) {
@@ -106,7 +154,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
     } else {
         float v[2] = {s1, s2};
         const float tot = ctn_block_sum<2>(v, red);
-        if (tid < 2) atomicAdd(a.esums + (int64_t)b * 2 + tid, (double)tot);
+        if (tid < 2) atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
     }
 }
 
@@ -121,6 +169,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
                                                      const int lw, const int H) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = 5 + 2 * P;
+    constexpr int NITB = 3;
     __shared__ float red[(NV > 3 ? NV : 3) * (NTH / 64)];
     float* D = lds;
     float* Xh = lds + lw;
@@ -132,8 +181,19 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
     const float a2 = a.alpha2 ? a.alpha2[0] : 1.f;
     const bool obwd = (a.oflags & CTN_XF_NORMBWD) != 0;
     const bool inorm = (a.xflags & CTN_XF_NORM) != 0;
+    const bool iprelu = (a.xflags & CTN_XF_PRELU) != 0;
     const int cend = min(c0 + CG, a.C);
     const int t_end = min(t0 + TT, T);
+    const int lw4 = lw / 4;
+    float m2h = 0.f, r2h = 1.f, c1h = 0.f, c2h = 0.f, m1h = 0.f, r1h = 1.f;
+    if (obwd && a.sst2 == 0) {
+        const int64_t si = (int64_t)b * a.ssb2;
+        m2h = a.mean2[si]; r2h = a.rstd2[si]; c1h = a.c1_2[si]; c2h = a.c2_2[si];
+    }
+    if (inorm && a.sst1 == 0) {
+        m1h = a.mean1[(int64_t)b * a.ssb1];
+        r1h = a.rstd1[(int64_t)b * a.ssb1];
+    }
 
     float dalpha2 = 0.f, s1 = 0.f, s2 = 0.f;
     float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
@@ -144,46 +204,67 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
         const float* xrow = a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx;
         const float g2 = obwd ? a.gamma2[c] : 1.f;
         float dgamma2 = 0.f, dbeta2 = 0.f, dbias = 0.f;
-        // ---- stage D and Xh
-        for (int i4 = tid; i4 < lw / 4; i4 += NTH) {
-            const int t = tA + 4 * i4;
-            f32x4 dv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < T) {
-                const f32x4 dn = ctn_ld4(dnrow + t);
-                const f32x4 x = ctn_ld4(xrow + t);
-                f32x4 y2 = {0.f, 0.f, 0.f, 0.f};
-                if (obwd) y2 = ctn_ld4(y2row + t);
+        // ---- stage D and Xh (all loads of a round first)
+        for (int r0 = 0; r0 < lw4; r0 += NITB * NTH) {
+            f32x4 vdn[NITB], vx[NITB], vy[NITB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool valid = t + e < T;
-                    const bool interior = valid && t + e >= t0 && t + e < t_end;
-                    float dy = dn[e];
-                    if (obwd) {
-                        const int64_t si = (int64_t)b * a.ssb2 + (int64_t)min(t + e, T - 1) * a.sst2;
-                        const float mean = a.mean2[si], rstd = a.rstd2[si];
-                        const float u = ctn_prelu(y2[e], a2);
-                        const float xc = u - mean;
-                        const float du = g2 * dn[e] * rstd + a.c1_2[si] + xc * a.c2_2[si];
-                        dy = y2[e] > 0.f ? du : a2 * du;
-                        if (interior) {
-                            dgamma2 += dn[e] * xc * rstd;
-                            dbeta2 += dn[e];
-                            if (!(y2[e] > 0.f)) dalpha2 += du * y2[e];
-                        }
-                    }
-                    if (interior) dbias += dy;
-                    dv[e] = valid ? dy : 0.f;
-                    float u1 = x[e];
-                    if (a.xflags & CTN_XF_PRELU) u1 = ctn_prelu(u1, a1);
-                    if (inorm) {
-                        const int64_t si = (int64_t)b * a.ssb1 + (int64_t)min(t + e, T - 1) * a.sst1;
-                        u1 = (u1 - a.mean1[si]) * a.rstd1[si];
-                    }
-                    xv[e] = valid ? u1 : 0.f;
+            for (int j = 0; j < NITB; ++j) {
+                const int i4 = r0 + tid + j * NTH;
+                const int t = tA + 4 * i4;
+                vdn[j] = vx[j] = vy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i4 < lw4 && t >= 0 && t < T) {
+                    vdn[j] = ctn_ld4(dnrow + t);
+                    vx[j] = ctn_ld4(xrow + t);
+                    if (obwd) vy[j] = ctn_ld4(y2row + t);
                 }
             }
-            ctn_st4(&D[4 * i4], dv);
-            ctn_st4(&Xh[4 * i4], xv);
+#pragma unroll
+            for (int j = 0; j < NITB; ++j) {
+                const int i4 = r0 + tid + j * NTH;
+                const int t = tA + 4 * i4;
+                if (i4 >= lw4) continue;
+                f32x4 dv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+                if (t >= 0 && t < T) {
+                    float mu2[4], rs2[4], k1[4], k2[4], mu1[4], rs1[4];
+                    if (obwd) {
+                        stat4(a.mean2, a.ssb2, a.sst2, b, t, T, m2h, mu2);
+                        stat4(a.rstd2, a.ssb2, a.sst2, b, t, T, r2h, rs2);
+                        stat4(a.c1_2, a.ssb2, a.sst2, b, t, T, c1h, k1);
+                        stat4(a.c2_2, a.ssb2, a.sst2, b, t, T, c2h, k2);
+                    }
+                    if (inorm) {
+                        stat4(a.mean1, a.ssb1, a.sst1, b, t, T, m1h, mu1);
+                        stat4(a.rstd1, a.ssb1, a.sst1, b, t, T, r1h, rs1);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool valid = t + e < T;
+                        const bool interior = valid && t + e >= t0 && t + e < t_end;
+                        const float dn = vdn[j][e];
+                        float dy = dn;
+                        if (obwd) {
+                            const float y2 = vy[j][e];
+                            const float u = ctn_prelu(y2, a2);
+                            const float xc = u - mu2[e];
+                            const float du = g2 * dn * rs2[e] + k1[e] + xc * k2[e];
+                            dy = y2 > 0.f ? du : a2 * du;
+                            if (interior) {
+                                dgamma2 += dn * xc * rs2[e];
+                                dbeta2 += dn;
+                                if (!(y2 > 0.f)) dalpha2 += du * y2;
+                            }
+                        }
+                        if (interior) dbias += dy;
+                        dv[e] = valid ? dy : 0.f;
+                        float u1 = vx[j][e];
+                        if (iprelu) u1 = ctn_prelu(u1, a1);
+                        if (inorm) u1 = (u1 - mu1[e]) * rs1[e];
+                        xv[e] = valid ? u1 : 0.f;
+                    }
+                }
+                ctn_st4(&D[4 * i4], dv);
+                ctn_st4(&Xh[4 * i4], xv);
+            }
         }
         __syncthreads();
         // ---- input gradient, weight gradient, norm-1 reductions
@@ -199,30 +280,33 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
         float* dxrow = a.dx + (int64_t)b * a.dxbs + (int64_t)c * a.lddx;
         for (int t = t0 + 4 * tid; t < t_end; t += 4 * NTH) {
             const int i0 = t - tA;
-            f32x4 o;
+            const f32x4 dy4 = ctn_ld4(&D[i0]);
+            const f32x4 xh4 = ctn_ld4(&Xh[i0]);
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const f32x4 dk = lds_read4(D, i0 - k * d + padL);
+                const f32x4 xk = lds_read4(Xh, i0 + k * d - padL);
+                o += w[k] * dk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ti = t + e + k * d - padL;
+                    dwa[k] += dy4[e] * xk[e];
+                    dwb[k] += (ti >= 0 && ti < T) ? dy4[e] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float acc = 0.f;
-                const float dy = D[i0 + e];
-#pragma unroll
-                for (int k = 0; k < P; ++k) {
-                    acc += w[k] * D[i0 + e - k * d + padL];
-                    const int ti = t + e + k * d - padL;
-                    dwa[k] += dy * Xh[i0 + e + k * d - padL];
-                    dwb[k] += (ti >= 0 && ti < T) ? dy : 0.f;
-                }
-                o[e] = acc;
                 if (t + e < T) {
-                    const float xh = Xh[i0 + e];
-                    const float g = g1 * acc;
-                    dgamma1 += acc * xh;
-                    dbeta1 += acc;
+                    const float g = g1 * o[e];
+                    dgamma1 += o[e] * xh4[e];
+                    dbeta1 += o[e];
                     if (a.cln) {
                         cs1[e] += g;
-                        cs2[e] += g * xh;
+                        cs2[e] += g * xh4[e];
                     } else {
                         s1 += g;
-                        s2 += g * xh;
+                        s2 += g * xh4[e];
                     }
                 }
             }
@@ -249,8 +333,8 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
     {
         float v[3] = {dalpha2, s1, s2};
         const float tot = ctn_block_sum<3>(v, red);
-        if (tid == 0 && obwd && a.dalpha2) atomicAdd(a.dalpha2, (double)tot);
-        if (!a.cln && a.isums && (tid == 1 || tid == 2)) atomicAdd(a.isums + (int64_t)b * 2 + (tid - 1), (double)tot);
+        if (tid == 0 && obwd && a.dalpha2) atomicAdd(a.dalpha2 + ctn_slot(), (double)tot);
+        if (!a.cln && a.isums && (tid == 1 || tid == 2)) atomicAdd(a.isums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + (tid - 1), (double)tot);
     }
     if (a.cln && a.icol) {
         const int t = t0 + 4 * tid;
@@ -276,7 +360,7 @@ void pick_tile(int T, int halo2, bool cln, int lds_rows, int* CG, int* TT, int* 
     if (cln) tt = tt < 4 * NTH ? tt : 4 * NTH;
     while (tt + halo2 + 3 > max_floats && tt > 256) tt = ((tt / 2) + 3) & ~3;
     *TT = tt;
-    *lw = (tt + halo2 + 3 + 3) & ~3;
+    *lw = ((tt + halo2 + 3 + 3) & ~3) + 4;   // + 4: slack for the unaligned two-vector tap reads
     *CG = cln ? 8 : 1;
 }
 

@@ -371,9 +371,9 @@ __global__ __launch_bounds__(NTH) void gemm_nn_kernel(const ctn_gemm_nn_args a, 
         float v[2] = {s1, s2};
         const float tot = ctn_block_sum<2>(v, red);
         if (emode == CTN_EPI_PRELUBWD) {
-            if (tid == 0 && a.esums) atomicAdd(a.esums, (double)tot);
+            if (tid == 0 && a.esums) atomicAdd(a.esums + ctn_slot(), (double)tot);
         } else if (tid < 2) {
-            atomicAdd(a.esums + (int64_t)b * 2 + tid, (double)tot);
+            atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
         }
     }
 }
@@ -664,9 +664,9 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
         float v[2] = {s1, s2};
         const float tot = ctn_block_sum<2>(v, red);
         if (emode == CTN_EPI_PRELUBWD) {
-            if (tid == 0 && a.esums) atomicAdd(a.esums, (double)tot);
+            if (tid == 0 && a.esums) atomicAdd(a.esums + ctn_slot(), (double)tot);
         } else if (tid < 2) {
-            atomicAdd(a.esums + (int64_t)b * 2 + tid, (double)tot);
+            atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
         }
     }
 }

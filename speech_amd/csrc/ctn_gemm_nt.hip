@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(const ctn_gemm_nt_args a, 
     if (BWD && a.a_dalpha != nullptr) {
         float v[1] = {do_dalpha ? dalpha : 0.f};
         const float tot = ctn_block_sum<1>(v, red);
-        if (tid == 0 && do_dalpha) atomicAdd(a.a_dalpha, (double)tot);
+        if (tid == 0 && do_dalpha) atomicAdd(a.a_dalpha + ctn_slot(), (double)tot);
     }
 }
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NT) void norm_stats_kernel(const float* __restrict_
     } else {
         float v[2] = {s1[0] + s1[1] + s1[2] + s1[3], s2[0] + s2[1] + s2[2] + s2[3]};
         float tot = ctn_block_sum<2>(v, red);
-        if (threadIdx.x < 2) atomicAdd(sums + (int64_t)b * 2 + threadIdx.x, (double)tot);
+        if (threadIdx.x < 2) atomicAdd(sums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + threadIdx.x, (double)tot);
     }
 }
 
@@ -80,8 +80,13 @@ __global__ void gln_finalize_kernel(const double* __restrict__ sums, int batch, 
                                     float* mean, float* rstd) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    const double m = sums[2 * b] / count;
-    double var = sums[2 * b + 1] / count - m * m;
+    double S1 = 0.0, S2 = 0.0;
+    for (int s = 0; s < CTN_STAT_SLOTS; ++s) {
+        S1 += sums[((int64_t)b * CTN_STAT_SLOTS + s) * 2];
+        S2 += sums[((int64_t)b * CTN_STAT_SLOTS + s) * 2 + 1];
+    }
+    const double m = S1 / count;
+    double var = S2 / count - m * m;
     if (var < 0.0) var = 0.0;
     mean[b] = (float)m;
     rstd[b] = (float)(1.0 / sqrt(var + (double)eps));
@@ -92,8 +97,13 @@ __global__ void gln_bwd_coefs_kernel(const double* __restrict__ sums, const floa
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const double r = rstd[b];
-    c1[b] = (float)(-r * sums[2 * b] / count);
-    c2[b] = (float)(-r * r * sums[2 * b + 1] / count);
+    double S1 = 0.0, S2 = 0.0;
+    for (int s = 0; s < CTN_STAT_SLOTS; ++s) {
+        S1 += sums[((int64_t)b * CTN_STAT_SLOTS + s) * 2];
+        S2 += sums[((int64_t)b * CTN_STAT_SLOTS + s) * 2 + 1];
+    }
+    c1[b] = (float)(-r * S1 / count);
+    c2[b] = (float)(-r * r * S2 / count);
 }
 
 // Block-wide exclusive scan of one double per thread (1024 threads); returns the exclusive prefix and
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(NT) void norm_bwd_reduce_kernel(const float* __rest
         const int c = c0 + (i >> 1);
         if (c < C) atomicAdd(((i & 1) ? dbeta : dgamma) + c, tot);
     } else if (i < 2 * CG + 2 && !col) {
-        atomicAdd(sums + (int64_t)b * 2 + (i - 2 * CG), (double)tot);
+        atomicAdd(sums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + (i - 2 * CG), (double)tot);
     }
 }
 
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(NT) void norm_bwd_apply_kernel(const float* __restr
     if (dalpha) {
         float v[1] = {da};
         float tot = ctn_block_sum<1>(v, red);
-        if (threadIdx.x == 0) atomicAdd(dalpha, (double)tot);
+        if (threadIdx.x == 0) atomicAdd(dalpha + ctn_slot(), (double)tot);
     }
 }
 

@@ -50,12 +50,13 @@ class GradSink:
         return None if p is None else self.views[self._index[id(p)]]
 
     def alpha_slot(self, p):
-        """fp64 accumulator (1-element view) for PReLU slope p."""
+        """fp64 slot-replicated accumulator (STAT_SLOTS doubles) for PReLU slope p."""
         if self.dalpha is None:
-            self.dalpha = torch.zeros(len(self.params), device=self.flat.device, dtype=torch.float64)
+            self.dalpha = torch.zeros((len(self.params), ops._lib.STAT_SLOTS), device=self.flat.device,
+                                      dtype=torch.float64)
         i = self._index[id(p)]
         self._alpha.append(i)
-        return self.dalpha[i:i + 1]
+        return self.dalpha[i]
 
     def finish(self):
         if self._alpha:
@@ -63,7 +64,7 @@ class GradSink:
             dev = self.flat.device
             src = torch.tensor(idx, device=dev, dtype=torch.long)
             dst = torch.tensor([self.offsets[i] for i in idx], device=dev, dtype=torch.long)
-            self.flat.index_copy_(0, dst, self.dalpha.index_select(0, src).float())
+            self.flat.index_copy_(0, dst, self.dalpha.index_select(0, src).sum(dim=1).float())
         return self.views
 
 

@@ -69,7 +69,8 @@ class Stat:
 
 
 class Accum:
-    """Zeroed accumulators for one norm's statistics: double (B, 2) for gLN, float (B, 2, ld) for cLN."""
+    """Zeroed accumulators for one norm's statistics: double (B, STAT_SLOTS, 2) for gLN (slot-replicated, the
+    value is the sum over slots), float (B, 2, ld) for cLN."""
 
     __slots__ = ("sums", "col", "ld")
 
@@ -81,7 +82,7 @@ class Accum:
         else:
             self.ld = 0
             self.col = None
-            self.sums = torch.zeros((B, 2), device=device, dtype=torch.float64)
+            self.sums = torch.zeros((B, _lib.STAT_SLOTS, 2), device=device, dtype=torch.float64)
 
 
 # ------------------------------------------------------------------------------------------------ norms

@@ -86,7 +86,7 @@ for name, M, N, bwd in [("dW1   M512 N128 NORMBWD A", 512, 128, True), ("heads M
     rs = torch.zeros(M, device=dev)
     if bwd:
         A2 = act(M)
-        da = torch.zeros(1, device=dev, dtype=torch.float64)
+        da = torch.zeros(32, device=dev, dtype=torch.float64)
         fn = lambda: ops.gemm_nt(M, N, T, B, A, Bm, Cw, N, aflags=4, A2=A2, a_alpha=alpha, a_stat=st, a_gamma=g,
                                  a_rowsum=rs, a_dalpha=da)
     else:
@@ -112,7 +112,7 @@ for d in (1, 8, 128):
     dn2, dx = act(H), act(H)
     dw, db = torch.zeros(H, 3, device=dev), torch.zeros(H, device=dev)
     dg1, db1, dg2, db2 = (torch.zeros(H, device=dev) for _ in range(4))
-    da2 = torch.zeros(1, device=dev, dtype=torch.float64)
+    da2 = torch.zeros(32, device=dev, dtype=torch.float64)
     iacc = ops.Accum(B, T, False, dev)
     dt = timeit(lambda: ops.dw_bwd(dn2, x, w, dw, db, dx, d, d, xflags=3, alpha1=alpha, stat1=st, gamma1=g, beta1=be,
                                    dgamma1=dg1, dbeta1=db1, iacc=iacc, y2=y, alpha2=alpha, stat2=st, gamma2=g,

@@ -71,6 +71,11 @@ int ctn_sizeof_gemm_nt_args(void);
 int ctn_sizeof_dw_fwd_args(void);
 int ctn_sizeof_dw_bwd_args(void);
 
+/* Tuning aid without a counterpart in the reference: forces the column width of the pointwise-GEMM output tile
+ * (64 or 128; 0 = choose per launch, the default).  Results agree across widths to fp32 summation order.
+ * Process-wide; returns CTN_ERR_ARG for any other value. */
+int ctn_gemm_nn_set_tile(int width);
+
 /* dst[k * ldd + coff + m] = src[m * K + k]  (m < M, k < K).  Lays a Conv1d(kernel_size=1) weight
  * (M_out, K_in) out k-major for ctn_gemm_nn. */
 int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64_t coff, void* stream);

@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctn_hip.so")
+LIB_PATH = os.environ.get("CTN_LIB", os.path.join(_HERE, "libctn_hip.so"))   # CTN_LIB: diagnostic builds only
 
 XF_PRELU, XF_NORM, XF_NORMBWD = 1, 2, 4
 STAT_SLOTS = 32          # CTN_STAT_SLOTS of include/ctn.h
@@ -112,6 +112,7 @@ class DwBwdArgs(C.Structure):
 PROTOTYPES = {
     "ctn_version": (C.c_char_p, []),
     "ctn_last_error": (C.c_char_p, []),
+    "ctn_gemm_nn_set_tile": (C.c_int, [C.c_int]),
     "ctn_sizeof_gemm_nn_args": (C.c_int, []),
     "ctn_sizeof_gemm_nt_args": (C.c_int, []),
     "ctn_sizeof_dw_fwd_args": (C.c_int, []),

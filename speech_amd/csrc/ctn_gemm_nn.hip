@@ -11,6 +11,8 @@
 // MFMA 32x32x2 f32 lane maps (l = lane, h = l >> 5):
 //   A operand: A[i = l & 31][k = h]     B operand: B[k = h][j = l & 31]
 //   D: column j = l & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * h for accumulator register r in [0, 16).
+#include <stdlib.h>
+
 #include "ctn_common.h"
 
 namespace {
@@ -381,28 +383,30 @@ __global__ __launch_bounds__(NTH) void gemm_nn_kernel(const ctn_gemm_nn_args a, 
 // ================================================================================================
 // Fast path for 16-byte-aligned operands and M % 4 == 0 (every paper-config shape).
 //
-// 128 x 128 output tile, BK = 16, 4 waves of 64 x 64.  Operand tiles go global -> LDS directly
-// (global_load_lds_dwordx4, no staging registers) into two buffers, so the loads of k-tile kt+1 are in
-// flight while the MFMAs of k-tile kt run, with one barrier per k-tile.  The operand transform is applied
-// to the B fragment right after its ds_read (per-frame statistics live in registers, per-channel
-// gamma/beta in LDS), so it rides in the VALU slots between MFMAs.  The accumulators leave through LDS:
-// each thread then handles float4s of whole rows, which makes every epilogue load/store a coalesced
-// 16-byte access and keeps register use low enough for several resident blocks per CU.
+// 128 x FBN_ output tile (FBN_ = 128 or 64), BK = 16, 4 waves of 64 x FBN_/2.  Operand tiles go
+// global -> LDS directly (global_load_lds_dwordx4, no staging registers) into two buffers, so the loads of
+// k-tile kt+1 are in flight while the MFMAs of k-tile kt run, with one barrier per k-tile.  The operand
+// transform (template flags XF, so the inner loop has no branches) is applied to the B fragment right
+// after its ds_read (per-frame statistics live in registers, per-channel gamma/beta in LDS), so it rides
+// in the VALU slots between MFMAs.  The accumulators leave through LDS: each thread then handles float4s of
+// whole rows, which makes every epilogue load/store a coalesced 16-byte access and keeps register use low
+// enough for several resident blocks per CU.  These GEMMs sit close to the roofline ridge (51 FLOP/B for
+// M=512,K=128), so the stores of one block have to overlap the MFMAs of another: the narrow tile gives
+// several generations of blocks per launch, which takes co-resident blocks out of lockstep.
 // ================================================================================================
-constexpr int FBM = 128, FBN = 128, FBK = 16;
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+constexpr int FBM = 128, FBK = 16;
 
-#define CTN_GLDS16(gp, lp)                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp),        \
-                                     (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
-
-template <bool BWD>
+template <int FBN_, int XF, bool BWD>
 __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
     // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int TILE_A = FBK * FBM, TILE_X = FBK * FBN;
+    constexpr int TILE_A = FBK * FBM, TILE_X = FBK * FBN_;
     constexpr int BUF = TILE_A + TILE_X + (BWD ? TILE_X : 0);
+    constexpr int WN = FBN_ / 2, NJ = WN / 32;            // wave tile 64 x WN = 2 x NJ MFMA tiles
+    constexpr int XLPR = FBN_ / 4;                        // lanes per X-tile row in a 1 KiB piece
+    constexpr int XRP = 64 / XLPR;                        // X-tile rows per piece
+    constexpr int XPW = (FBK / XRP) / 4;                  // X pieces per wave
     __shared__ float red[2 * (NTH / 64)];
 
     const int total = gridDim.x, hb = blockIdx.x;
@@ -412,30 +416,30 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
     const int rest = lb / tiles_m;
     const int tile_n = rest % tiles_n;
     const int b = rest / tiles_n;
-    const int m_blk = tile_m * FBM, t_blk = tile_n * FBN;
+    const int m_blk = tile_m * FBM, t_blk = tile_n * FBN_;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
     const int M = a.M, T = a.T, K = a.K, K1 = a.K1;
-    const int xflags = a.xflags;
     const float alpha = a.alpha ? a.alpha[0] : 1.f;
     const int nk = (K + FBK - 1) / FBK;
     const int Kp = nk * FBK;
     float* Gs = lds + 2 * BUF;
     float* Bes = Gs + Kp;
-    const bool has_norm = (xflags & (CTN_XF_NORM | CTN_XF_NORMBWD)) != 0;
+    constexpr bool has_norm = BWD || (XF & CTN_XF_NORM) != 0;
     if (has_norm) {
         for (int k = tid; k < Kp; k += NTH) {
             Gs[k] = k < K ? a.gamma[k] : 0.f;
             Bes[k] = (!BWD && k < K) ? a.beta[k] : 0.f;
         }
     }
-    // per-frame statistics of this lane's two columns
-    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f}, c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
-    if (has_norm) {
+    // per-frame statistics of this lane's columns
+    float mean[NJ], rstd[NJ], c1[NJ], c2[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
+        mean[j] = 0.f, rstd[j] = 1.f, c1[j] = 0.f, c2[j] = 0.f;
+        if (has_norm) {
             const int t = min(t_blk + wn0 + j * 32 + l31, T - 1);
             const int64_t si = (int64_t)b * a.ssb + (int64_t)t * a.sst;
             mean[j] = a.mean[si];
@@ -447,57 +451,85 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
         }
     }
 
-    // each wave issues 1 KiB pieces: piece p covers tile rows 2p, 2p+1 (32 lanes x 16 B per row)
-    const int prow = lane >> 5, pcol = (lane & 31) * 4;
+    // Tiles are fetched with buffer_load_dwordx4 ... lds: the descriptor and the k-dependent part of the address
+    // (soffset) are scalar, the per-lane part (voffset) is loop-invariant, so a k-tile's loads cost no vector
+    // instructions -- vector issue slots beside the MFMAs are what limits this loop.  A lane whose float4 lies
+    // outside the matrix gets a voffset beyond the descriptor's range and reads zeros.
+    constexpr int RS_BYTES = 0x40000000;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ldA1 = a.lda, ldA2 = a.lda2, ldX1 = a.ldx, ldXb = a.ldxb, ldX2 = a.ldx2;
+    const auto rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, RS_BYTES, 0x00020000);
+    const auto rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A2 ? a.A2 : a.A), 0, RS_BYTES, 0x00020000);
+    const auto rX1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (int64_t)b * a.xbs), 0, RS_BYTES, 0x00020000);
+    const auto rXb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Xb ? a.Xb + (int64_t)b * a.xbbs : a.X), 0, RS_BYTES,
+                                                       0x00020000);
+    const auto rX2 = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? a.X2 + (int64_t)b * a.x2bs : a.X), 0, RS_BYTES,
+                                                       0x00020000);
+    // an A piece covers tile rows 2p, 2p+1 (32 lanes x 16 B per row), an X piece XRP rows of FBN_ floats
+    const int arow = lane >> 5, acol = (lane & 31) * 4;
+    const int xrow = lane / XLPR, xcol = (lane % XLPR) * 4;
+    const bool m_ok = m_blk + acol < M;
+    const int tcol = t_blk + xcol;
+    const int voA1 = m_ok ? (arow * ldA1 + m_blk + acol) * 4 : RS_BYTES;
+    const int voA2 = m_ok ? (arow * ldA2 + m_blk + acol) * 4 : RS_BYTES;
+    const int voX1 = tcol < ldX1 ? (xrow * ldX1 + tcol) * 4 : RS_BYTES;
+    const int voXb = tcol < ldXb ? (xrow * ldXb + tcol) * 4 : RS_BYTES;
+    const int voX2 = tcol < ldX2 ? (xrow * ldX2 + tcol) * 4 : RS_BYTES;
+#define CTN_BLDS16(rs, lp, vo, so) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
     auto issue = [&](int kt, int buf) {
         float* base = lds + buf * BUF;
         const int k0 = kt * FBK;
+        if (k0 < K1) {
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {                 // A tile: 8 pieces, 2 per wave
-            const int p = wave * 2 + pp;
-            const int k = k0 + 2 * p + prow, m = m_blk + pcol;
-            const float* src = g_zero16;
-            if (k < K && m < M) src = (k < K1) ? a.A + (int64_t)k * a.lda + m : a.A2 + (int64_t)(k - K1) * a.lda2 + m;
-            CTN_GLDS16(src, base + p * 256);
-        }
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {                 // X tile
-            const int p = wave * 2 + pp;
-            const int k = k0 + 2 * p + prow, t = t_blk + pcol;
-            const float* src = g_zero16;
-            if (k < K) {
-                if (k < K1) {
-                    if (t < a.ldx) src = a.X + (int64_t)b * a.xbs + (int64_t)k * a.ldx + t;
-                } else if (t < a.ldxb) {
-                    src = a.Xb + (int64_t)b * a.xbbs + (int64_t)(k - K1) * a.ldxb + t;
-                }
+            for (int pp = 0; pp < 2; ++pp) {             // A tile: 8 pieces, 2 per wave
+                const int p = wv * 2 + pp;
+                CTN_BLDS16(rA1, base + p * 256, voA1, (k0 + 2 * p) * ldA1 * 4);
             }
-            CTN_GLDS16(src, base + TILE_A + p * 256);
+#pragma unroll
+            for (int pp = 0; pp < XPW; ++pp) {           // X tile
+                const int p = wv * XPW + pp;
+                CTN_BLDS16(rX1, base + TILE_A + p * 256, voX1, (k0 + XRP * p) * ldX1 * 4);
+            }
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int p = wv * 2 + pp;
+                CTN_BLDS16(rA2, base + p * 256, voA2, (k0 - K1 + 2 * p) * ldA2 * 4);
+            }
+#pragma unroll
+            for (int pp = 0; pp < XPW; ++pp) {
+                const int p = wv * XPW + pp;
+                CTN_BLDS16(rXb, base + TILE_A + p * 256, voXb, (k0 - K1 + XRP * p) * ldXb * 4);
+            }
         }
         if (BWD) {
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int p = wave * 2 + pp;
-                const int k = k0 + 2 * p + prow, t = t_blk + pcol;
-                const float* src = g_zero16;
-                if (k < K && t < a.ldx2) src = a.X2 + (int64_t)b * a.x2bs + (int64_t)k * a.ldx2 + t;
-                CTN_GLDS16(src, base + TILE_A + TILE_X + p * 256);
+            for (int pp = 0; pp < XPW; ++pp) {
+                const int p = wv * XPW + pp;
+                CTN_BLDS16(rX2, base + TILE_A + TILE_X + p * 256, voX2, (k0 + XRP * p) * ldX2 * 4);
             }
         }
     };
+#undef CTN_BLDS16
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();          // tile kt has landed (vmcnt drained before the barrier); buffer (kt+1)&1 is free
+        // Every wave's pieces of tile kt must have landed before ANY wave reads the tile: drain this wave's
+        // LDS-DMA loads explicitly, the compiler does not always put the vmcnt wait ahead of the barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // tile kt is complete; buffer (kt+1)&1 is free
+#ifndef CTN_DBG_NO_LOADS
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+#endif
         const float* As = lds + (kt & 1) * BUF;
         const float* Xs = As + TILE_A;
         const float* X2s = Xs + TILE_X;
@@ -505,45 +537,64 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
 #pragma unroll
         for (int kk = 0; kk < FBK / 2; ++kk) {
             const int k = 2 * kk + half;
-            float av[2], bv[2];
+            float av[2], bv[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) av[i] = As[k * FBM + wm0 + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = Xs[k * FBN + wn0 + j * 32 + l31];
+            for (int j = 0; j < NJ; ++j) bv[j] = Xs[k * FBN_ + wn0 + j * 32 + l31];
             if (BWD) {
                 const float g = Gs[k0 + k];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float y = X2s[k * FBN + wn0 + j * 32 + l31];
+                for (int j = 0; j < NJ; ++j) {
+                    const float y = X2s[k * FBN_ + wn0 + j * 32 + l31];
                     const float u = ctn_prelu(y, alpha);
                     const float du = g * bv[j] * rstd[j] + c1[j] + (u - mean[j]) * c2[j];
                     bv[j] = y > 0.f ? du : alpha * du;
                 }
             } else {
-                if (xflags & CTN_XF_PRELU) {
+                if (XF & CTN_XF_PRELU) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bv[j] = ctn_prelu(bv[j], alpha);
+                    for (int j = 0; j < NJ; ++j) bv[j] = ctn_prelu(bv[j], alpha);
                 }
-                if (xflags & CTN_XF_NORM) {
+                if (XF & CTN_XF_NORM) {
                     const float g = Gs[k0 + k], be = Bes[k0 + k];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bv[j] = (bv[j] - mean[j]) * rstd[j] * g + be;
+                    for (int j = 0; j < NJ; ++j) bv[j] = (bv[j] - mean[j]) * rstd[j] * g + be;
                 }
             }
+#ifndef CTN_DBG_NO_MFMA
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+#else
+            acc[0][0][kk] += av[0] + av[1] + bv[0] + bv[NJ - 1];
+#endif
         }
     }
     __syncthreads();              // every wave is done with the tiles: reuse them as epilogue staging
+#ifdef CTN_DBG_NO_EPILOGUE
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+        if (keep == 123.456f) a.Y[0] = keep;
+        return;
+    }
+#endif
 
     // ------------------------------------------------------------------ epilogue through LDS
-    float* stg = lds;             // 64 x 128 floats = 32 KiB <= 2 * BUF
+    float* stg = lds;             // 64 x FBN_ floats <= 2 * BUF
+    constexpr int TPR = FBN_ / 4;                 // threads per staged row
+    constexpr int RS = NTH / TPR;                 // rows per sweep of the block
     const int emode = a.emode;
     const float ea = a.ealpha ? a.ealpha[0] : 1.f;
-    const int c4 = (tid & 31) * 4, r0 = tid >> 5;          // this thread: columns c4..c4+3, rows r0 + 8q
+    const int c4 = (tid % TPR) * 4, r0 = tid / TPR;        // this thread: columns c4..c4+3, rows r0 + RS q
     const int t = t_blk + c4;
     const bool col_ok = t < a.ldy;                          // the float4 lies inside the row
     float em[4] = {0, 0, 0, 0}, er[4] = {1, 1, 1, 1};
@@ -564,19 +615,19 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN + wn0 + j * 32 + l31] = acc[i][j][r];
+                        stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + j * 32 + l31] = acc[i][j][r];
         }
         __syncthreads();
         if (col_ok) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = r0 + 8 * q;
+            for (int q = 0; q < 64 / RS; ++q) {
+                const int row = r0 + RS * q;
                 const int m = m_blk + pass * 64 + row;
                 if (m >= M) continue;
-                f32x4 v = ctn_ld4(&stg[row * FBN + c4]);
+                f32x4 v = ctn_ld4(&stg[row * FBN_ + c4]);
                 if (emode == CTN_EPI_HEADS) {
                     if (m < a.Mo) {
                         const float bsv = a.bias ? a.bias[m] : 0.f;
@@ -641,19 +692,21 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
         __syncthreads();
     }
     if (want_stats) {
-        if (a.ecol) {            // per-frame sums: fold the 8 row groups through LDS, one atomic per frame
+        if (a.ecol) {            // per-frame sums: fold the RS row groups through LDS, one atomic per frame
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                stg[(r0 * 2 + 0) * FBN + c4 + e] = cs1[e];
-                stg[(r0 * 2 + 1) * FBN + c4 + e] = cs2[e];
+                stg[(r0 * 2 + 0) * FBN_ + c4 + e] = cs1[e];
+                stg[(r0 * 2 + 1) * FBN_ + c4 + e] = cs2[e];
             }
             __syncthreads();
-            const int col = tid & 127, which = tid >> 7;
-            float tot = 0.f;
+            const int col = tid % FBN_, which = tid / FBN_;
+            if (which < 2) {
+                float tot = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) tot += stg[(g * 2 + which) * FBN + col];
-            const int tc = t_blk + col;
-            if (tc < T) atomicAdd(a.ecol + (int64_t)b * a.ecol_bs + (int64_t)which * a.ecol_ld + tc, tot);
+                for (int g = 0; g < RS; ++g) tot += stg[(g * 2 + which) * FBN_ + col];
+                const int tc = t_blk + col;
+                if (tc < T) atomicAdd(a.ecol + (int64_t)b * a.ecol_bs + (int64_t)which * a.ecol_ld + tc, tot);
+            }
         } else {
             s1 = cs1[0] + cs1[1] + cs1[2] + cs1[3];
             s2 = cs2[0] + cs2[1] + cs2[2] + cs2[3];
@@ -672,6 +725,9 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
 }
 
 bool fast_ok(const ctn_gemm_nn_args& a) {
+#ifdef CTN_DBG_NO_FAST
+    return false;
+#endif
     auto al = [](const void* p) { return p == nullptr || ctn_aligned16(p); };
     if (a.M <= 64 || a.M % 4 != 0) return false;
     if (!ctn_aligned16(a.A) || a.lda % 4 != 0) return false;
@@ -680,12 +736,31 @@ bool fast_ok(const ctn_gemm_nn_args& a) {
     if (a.R && (!al(a.R) || a.ldr % 4 != 0 || a.rbs % 4 != 0 || a.ldr < a.ldy)) return false;
     if (a.Y2 && (!al(a.Y2) || a.ldy2 % 4 != 0 || a.y2bs % 4 != 0 || a.ldy2 < a.ldy)) return false;
     if (a.E && (!al(a.E) || a.lde % 4 != 0 || a.ebs % 4 != 0 || a.lde < a.ldy)) return false;
-    if ((int64_t)a.K > 4096) return false;
+    if ((int64_t)a.K > 4096 || a.K % FBK != 0 || a.K1 % FBK != 0) return false;
+    // byte offsets inside one operand (one batch item) must stay below the buffer descriptors' range
+    const int64_t lim = 0x40000000 / 4 - 4096;
+    if ((int64_t)a.K * a.lda >= lim || (int64_t)a.K * a.ldx >= lim) return false;
+    if (a.K1 < a.K && ((int64_t)a.K * a.lda2 >= lim || (int64_t)a.K * a.ldxb >= lim)) return false;
+    if ((a.xflags & CTN_XF_NORMBWD) && (int64_t)a.K * a.ldx2 >= lim) return false;
     return true;
 }
 
-int launch_fast(const ctn_gemm_nn_args& a, hipStream_t s) {
-    const int tiles_m = ctn_cdiv(a.M, FBM), tiles_n = ctn_cdiv(a.T, FBN);
+// Tile width: ctn_gemm_nn_set_tile() or CTN_GEMM_FBN=64|128 forces one (tuning aids); otherwise the narrow tile
+// unless the launch has so many 128-wide tiles that generations of blocks overlap anyway.
+int g_forced_fbn = -1;
+int pick_fbn(int64_t tiles128) {
+    if (g_forced_fbn < 0) {
+        const char* e = getenv("CTN_GEMM_FBN");
+        const int v = e ? atoi(e) : 0;
+        g_forced_fbn = (v == 64 || v == 128) ? v : 0;
+    }
+    if (g_forced_fbn) return g_forced_fbn;
+    return tiles128 >= 8192 ? 128 : 64;
+}
+
+template <int FBN_>
+int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
+    const int tiles_m = ctn_cdiv(a.M, FBM), tiles_n = ctn_cdiv(a.T, FBN_);
     const int64_t total = (int64_t)tiles_m * tiles_n * a.batch;
     if (total > 0x7fffffff) {
         ctn_set_error("ctn_gemm_nn: grid too large");
@@ -693,16 +768,37 @@ int launch_fast(const ctn_gemm_nn_args& a, hipStream_t s) {
     }
     const int Kp = ctn_cdiv(a.K, FBK) * FBK;
     const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
-    const size_t buf = (size_t)(FBK * FBM + FBK * FBN + (bwd ? FBK * FBN : 0));
+    const size_t buf = (size_t)(FBK * FBM + FBK * FBN_ + (bwd ? FBK * FBN_ : 0));
     size_t floats = 2 * buf + 2 * (size_t)Kp;
-    if (floats < 64 * FBN) floats = 64 * FBN;      // epilogue staging
+    if (floats < 64 * FBN_) floats = 64 * FBN_;      // epilogue staging
     const size_t shmem = floats * sizeof(float);
-    if (bwd)
-        hipLaunchKernelGGL((gemm_nn_fast_kernel<true>), dim3((unsigned)total), dim3(NTH), shmem, s, a, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((gemm_nn_fast_kernel<false>), dim3((unsigned)total), dim3(NTH), shmem, s, a, tiles_m,
-                           tiles_n);
+    const dim3 grid((unsigned)total), block(NTH);
+    if (bwd) {
+        hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
+        return CTN_OK;
+    }
+    switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {
+        case 0:
+            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, false>), grid, block, shmem, s, a, tiles_m, tiles_n);
+            break;
+        case CTN_XF_PRELU:
+            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU, false>), grid, block, shmem, s, a, tiles_m,
+                               tiles_n);
+            break;
+        case CTN_XF_NORM:
+            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_NORM, false>), grid, block, shmem, s, a, tiles_m,
+                               tiles_n);
+            break;
+        default:
+            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU | CTN_XF_NORM, false>), grid, block, shmem, s, a,
+                               tiles_m, tiles_n);
+    }
     return CTN_OK;
+}
+
+int launch_fast(const ctn_gemm_nn_args& a, hipStream_t s) {
+    const int64_t tiles128 = (int64_t)ctn_cdiv(a.M, FBM) * ctn_cdiv(a.T, 128) * a.batch;
+    return pick_fbn(tiles128) == 128 ? launch_fast_n<128>(a, s) : launch_fast_n<64>(a, s);
 }
 
 template <int BM, int WAVES_M>
@@ -723,6 +819,12 @@ int launch(const ctn_gemm_nn_args& a, int vecA, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int ctn_gemm_nn_set_tile(int width) {
+    CTN_REQUIRE(width == 0 || width == 64 || width == 128, "ctn_gemm_nn_set_tile: width must be 0, 64 or 128");
+    g_forced_fbn = width;
+    return CTN_OK;
+}
 
 extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
     CTN_REQUIRE(args, "ctn_gemm_nn: null args");

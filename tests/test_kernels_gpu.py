@@ -15,6 +15,21 @@ def dev():
     return torch.device("cuda:0")
 
 
+# "generic": dimensions the register-staged GEMM serves; "fast64"/"fast128": dimensions that qualify for the
+# LDS-DMA kernel (M > 64, M % 4 == 0, K % 16 == 0), with its output-tile width forced to 64 / 128 columns.
+PATHS = ["generic", "fast64", "fast128"]
+
+
+@pytest.fixture
+def gemm_path(request):
+    from speech_amd import _lib
+    lib = _lib.load()
+    path = request.param
+    assert lib.ctn_gemm_nn_set_tile({"generic": 0, "fast64": 64, "fast128": 128}[path]) == 0
+    yield path
+    lib.ctn_gemm_nn_set_tile(0)
+
+
 def act(t):
     from speech_amd import ops
     return ops.as_act(t.to(dev()).float())
@@ -68,8 +83,10 @@ def test_transpose():
 
 @pytest.mark.parametrize("M,K,T,batch", [(40, 24, 301, 2), (128, 128, 515, 2), (200, 130, 257, 1), (512, 128, 3999, 1),
                                          (32, 512, 100, 3), (64, 64, 64, 1)])
-def test_gemm_nn_plain(M, K, T, batch):
-    from speech_amd import ops
+@pytest.mark.parametrize("width", [64, 128])
+def test_gemm_nn_plain(M, K, T, batch, width):
+    from speech_amd import ops, _lib
+    _lib.load().ctn_gemm_nn_set_tile(width)
     W = rnd((M, K), 2)
     bias = rnd((M,), 3)
     X = rnd((batch, K, T), 4)
@@ -79,12 +96,14 @@ def test_gemm_nn_plain(M, K, T, batch):
     Y = ops.new_act(batch, M, T, dev())
     ops.gemm_nn(M, T, K, batch, Wt, M, act(X), Y, bias=bias.float().to(dev()))
     torch.cuda.synchronize()
+    _lib.load().ctn_gemm_nn_set_tile(0)
     assert_close(Y, ref, TOL, "gemm_nn")
 
 
-def test_gemm_nn_split_k_add_residual():
+@pytest.mark.parametrize("gemm_path", PATHS, indirect=True)
+def test_gemm_nn_split_k_add_residual(gemm_path):
     from speech_amd import ops
-    M, K1, K2, T, B = 48, 16, 24, 301, 2
+    M, K1, K2, T, B = (48, 16, 24, 301, 2) if gemm_path == "generic" else (72, 16, 32, 301, 2)
     Wa, Wb = rnd((K1, M), 5), rnd((K2, M), 6)       # already k-major
     Xa, Xb, R = rnd((B, K1, T), 7), rnd((B, K2, T), 8), rnd((B, M, T), 9)
     ref = torch.einsum("km,bkt->bmt", Wa, Xa) + torch.einsum("km,bkt->bmt", Wb, Xb) + R
@@ -95,10 +114,11 @@ def test_gemm_nn_split_k_add_residual():
     assert_close(Y, ref, TOL, "split-K + residual")
 
 
+@pytest.mark.parametrize("gemm_path", PATHS, indirect=True)
 @pytest.mark.parametrize("cln", [False, True])
-def test_gemm_nn_norm_on_load_heads_epilogue(cln):
+def test_gemm_nn_norm_on_load_heads_epilogue(cln, gemm_path):
     from speech_amd import ops
-    H, Bc, Sc, T, B = 40, 16, 24, 301, 2
+    H, Bc, Sc, T, B = (40, 16, 24, 301, 2) if gemm_path == "generic" else (48, 72, 64, 301, 2)
     y2 = rnd((B, H, T), 10) + 0.3
     alpha = torch.tensor([0.2], dtype=torch.float64)
     gamma, beta = 1 + 0.2 * rnd((H,), 11), 0.2 * rnd((H,), 12)
@@ -125,10 +145,11 @@ def test_gemm_nn_norm_on_load_heads_epilogue(cln):
         assert_close(skip, ref_skip + (skip0 if accumulate else 0), TOL, "heads skip")
 
 
+@pytest.mark.parametrize("gemm_path", PATHS, indirect=True)
 @pytest.mark.parametrize("cln", [False, True])
-def test_gemm_nn_stats_epilogue(cln):
+def test_gemm_nn_stats_epilogue(cln, gemm_path):
     from speech_amd import ops
-    M, K, T, B = 72, 16, 301, 2
+    M, K, T, B = (60, 20, 301, 2) if gemm_path == "generic" else (136, 32, 301, 2)
     W, bias, X = rnd((M, K), 20), rnd((M,), 21), rnd((B, K, T), 22)
     alpha = torch.tensor([0.25], dtype=torch.float64)
     ref = torch.einsum("mk,bkt->bmt", W, X) + bias.view(1, M, 1)
@@ -150,9 +171,10 @@ def test_gemm_nn_stats_epilogue(cln):
         assert_close(st.rstd, rstd.reshape(B), TOL, "rstd")
 
 
-def test_gemm_nn_sigmoid_and_prelu_bwd_epilogues():
+@pytest.mark.parametrize("gemm_path", PATHS, indirect=True)
+def test_gemm_nn_sigmoid_and_prelu_bwd_epilogues(gemm_path):
     from speech_amd import ops
-    M, K, T, B = 96, 24, 130, 2
+    M, K, T, B = (96, 24, 130, 2) if gemm_path == "generic" else (132, 32, 130, 2)
     W, bias, X = rnd((M, K), 30), rnd((M,), 31), rnd((B, K, T), 32)
     alpha = torch.tensor([0.3], dtype=torch.float64)
     f = lambda t: t.float().to(dev())
@@ -176,10 +198,11 @@ def test_gemm_nn_sigmoid_and_prelu_bwd_epilogues():
     assert_close(da.sum().reshape(1), ref_da.reshape(1), 1e-4, "dalpha")
 
 
+@pytest.mark.parametrize("gemm_path", PATHS, indirect=True)
 @pytest.mark.parametrize("cln", [False, True])
-def test_gemm_nn_normbwd_epilogue_and_load(cln):
+def test_gemm_nn_normbwd_epilogue_and_load(cln, gemm_path):
     from speech_amd import ops
-    H, K, T, B = 40, 24, 301, 2
+    H, K, T, B = (40, 24, 301, 2) if gemm_path == "generic" else (144, 32, 301, 2)
     f = lambda t: t.float().to(dev())
     W = rnd((K, H), 40)               # k-major already: dn = W^T-contract
     X = rnd((B, K, T), 41)
@@ -213,7 +236,7 @@ def test_gemm_nn_normbwd_epilogue_and_load(cln):
     nn_.backward(dn)
     dy_ref = yv.grad
     # NORMBWD on load feeding a second GEMM
-    M2 = 24
+    M2 = 24 if gemm_path == "generic" else 72
     W2 = rnd((H, M2), 44)
     R = rnd((B, M2, T), 45)
     ref2 = torch.einsum("km,bkt->bmt", W2, dy_ref) + R

@@ -272,3 +272,27 @@ def test_full_size_properties():
     loss_k, perm_k = crit(out * 3.0, sources)
     assert_close(loss_k, loss, 1e-5, "scale invariance")
     assert torch.equal(perm_k, perm)
+
+
+def test_paper_backward_is_reproducible():
+    """Three forward/backward passes of the paper configuration in one process give the same gradients up to
+    the order of the fp32/fp64 atomic additions (measured 5e-7): a missing wait or barrier in a kernel shows
+    up here as differences of 1e-3 and more, and only at sizes that put several workgroups on every CU."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    cfg = O.CONFIG_PAPER
+    first = None
+    for run in range(3):
+        model = load_state(build(cfg), cases.e2e_state(cfg))
+        mixture, sources = cases.e2e_batch(cfg, 2, 32000, 0)
+        out = model(mixture.to(dev()))
+        loss, _ = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        if first is None:
+            first = grads
+            continue
+        for k, v in grads.items():
+            scale = float(first[k].abs().max()) + 1e-30
+            assert float((v - first[k]).abs().max()) <= 2e-5 * scale, "run %d differs in %s" % (run, k)

@@ -9,6 +9,8 @@
 // ds_read_b128 and feeds them to 4 MFMAs (the two half-waves take alternate 4-frame groups, so every
 // frame is summed exactly once).  The A-operand loader can apply the norm/PReLU backward transform and
 // reduce the bias and PReLU-slope gradients on the way.
+#include <type_traits>
+
 #include "ctn_common.h"
 
 namespace {
@@ -234,6 +236,286 @@ void launch(const ctn_gemm_nt_args& a, hipStream_t s) {
                            tiles_n, nchunks);
 }
 
+// ================================================================================================
+// Fast path: TILE x TILE output tile (4 waves of TILE/2 x TILE/2), 16 frames per k-tile, operands fetched straight into LDS with
+// buffer_load_dwordx4 ... lds (scalar descriptor and k offset, loop-invariant per-lane offset: no vector
+// instructions per k-tile) into two buffers.  A DMA piece is 16 rows x 64 B written lane-linearly, so the
+// usual row padding is impossible; instead lane (row r, slot s) of a piece FETCHES the row's 16-byte frame
+// group s ^ ((r >> 2) & 3), and the fragment reads undo that XOR: each lane then gets 4 consecutive frames
+// of its row with one conflict-free ds_read_b128 and feeds them to 4 MFMAs (half-wave h owns frame groups
+// 2c + h, so every frame is summed once).  Operand transforms, the tail mask and the bias / PReLU-slope
+// reductions run on the fragments, in the shadow of the MFMAs.  Needs per-batch (not per-frame)
+// statistics, i.e. gLN; cumulative-norm launches and ragged shapes use the kernel above.
+// ================================================================================================
+constexpr int FK = 16;
+
+template <int TILE, bool BWD, int BXF>
+__global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
+                                                           const int tiles_n, const int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int FTILE = TILE * FK;                      // floats per operand tile
+    constexpr int BUF = FTILE * (BWD ? 3 : 2);           // A | B | (A2)
+    constexpr int WT = TILE / 2;                          // wave tile WT x WT
+    constexpr int TT = WT / 32;                           // MFMA tiles per wave and dimension
+    constexpr int PPW = TILE / 64;                        // DMA pieces per wave and operand tile
+    __shared__ float red[(NTH / 64)];
+
+    int lb = blockIdx.x;
+    const int tile_n = lb % tiles_n; lb /= tiles_n;
+    const int tile_m = lb % tiles_m; lb /= tiles_m;
+    const int chunk = lb % nchunks;
+    const int b = lb / nchunks;
+    const int m_blk = tile_m * TILE, n_blk = tile_n * TILE;
+    const int M = a.M, N = a.N, M1 = a.M1;
+    const int t_begin = chunk * a.kchunk, t_end = min(t_begin + a.kchunk, a.T);
+    const int nk = (t_end - t_begin + FK - 1) / FK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
+
+    constexpr int RS_BYTES = 0x40000000;
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A ? a.A + (int64_t)b * a.abs_ : a.Ab), 0, RS_BYTES,
+                                                      0x00020000);
+    const auto rAb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Ab ? a.Ab + (int64_t)b * a.abbs : a.A), 0, RS_BYTES,
+                                                       0x00020000);
+    const auto rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? a.A2 + (int64_t)b * a.a2bs : a.B), 0, RS_BYTES,
+                                                       0x00020000);
+    const auto rB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)b * a.bbs), 0, RS_BYTES, 0x00020000);
+    const int lda = a.lda, ldab = a.ldab, lda2 = a.lda2, ldb = a.ldb;
+    // DMA lane: row lane >> 2 of the piece, LDS slot lane & 3, fetching frame group slot ^ ((row >> 2) & 3)
+    const int prow = lane >> 2, pgrp = ((lane & 3) ^ ((lane >> 4) & 3)) * 4;
+    const int voA = (prow * lda + pgrp) * 4, voAb = (prow * ldab + pgrp) * 4;
+    const int voA2 = (prow * lda2 + pgrp) * 4, voB = (prow * ldb + pgrp) * 4;
+#define CTN_BLDS16(rs, lp, vo, so) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+    auto issue = [&](int t0, int buf) {
+        float* base = lds + buf * BUF;
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            const int p = wv * PPW + pp;
+            const int m = m_blk + 16 * p, n = n_blk + 16 * p;
+            if (m < M) {
+                if (m < M1)
+                    CTN_BLDS16(rA, base + p * 256, voA, (m * lda + t0) * 4);
+                else
+                    CTN_BLDS16(rAb, base + p * 256, voAb, ((m - M1) * ldab + t0) * 4);
+                if (BWD) CTN_BLDS16(rA2, base + 2 * FTILE + p * 256, voA2, (m * lda2 + t0) * 4);
+            }
+            if (n < N) CTN_BLDS16(rB, base + FTILE + p * 256, voB, (n * ldb + t0) * 4);
+        }
+    };
+#undef CTN_BLDS16
+
+    // per-lane row constants
+    const float a_alpha = a.a_alpha ? a.a_alpha[0] : 1.f;
+    const float b_alpha = a.b_alpha ? a.b_alpha[0] : 1.f;
+    float ag[TT], bg[TT], bb[TT];
+    bool rv[TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        ag[i] = 0.f, bg[i] = 1.f, bb[i] = 0.f;
+        const int m = m_blk + wm0 + i * 32 + l31;
+        rv[i] = m < M;
+        if (BWD && rv[i]) ag[i] = a.a_gamma[m];
+        const int n = n_blk + wn0 + i * 32 + l31;
+        if ((BXF & CTN_XF_NORM) && n < N) {
+            bg[i] = a.b_gamma[n];
+            bb[i] = a.b_beta[n];
+        }
+    }
+    float amean = 0.f, arstd = 1.f, ac1 = 0.f, ac2 = 0.f, bmean = 0.f, brstd = 1.f;
+    if (BWD) {
+        const int64_t si = (int64_t)b * a.a_ssb;
+        amean = a.a_mean[si]; arstd = a.a_rstd[si]; ac1 = a.a_c1[si]; ac2 = a.a_c2[si];
+    }
+    if (BXF & CTN_XF_NORM) {
+        const int64_t si = (int64_t)b * a.b_ssb;
+        bmean = a.b_mean[si]; brstd = a.b_rstd[si];
+    }
+    // the two waves of a tile row read the same A rows: one of them reduces, and only in the first tile column
+    const bool reducer = (tile_n == 0) && ((wave & 1) == 0);
+    const bool do_rowsum = reducer && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr);
+    const bool do_dalpha = BWD && reducer && (a.a_dalpha != nullptr);
+    float rowsum[TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) rowsum[i] = 0.f;
+    float dalpha = 0.f;
+
+    f32x16 acc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fsw = (l31 >> 2) & 3;
+    const int arow_off = (wm0 + l31) * FK, brow_off = (wn0 + l31) * FK;
+
+    auto compute = [&](const float* As, int t0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const float* Bs = As + FTILE;
+        const float* A2s = As + 2 * FTILE;
+#pragma unroll
+        for (int c = 0; c < FK / 8; ++c) {
+            const int grp = 2 * c + half;                 // logical frame group of this half-wave
+            const int so = ((grp ^ fsw) * 4);             // its LDS slot in this lane's rows
+            f32x4 av[TT], bv[TT];
+#pragma unroll
+            for (int i = 0; i < TT; ++i) av[i] = ctn_ld4(&As[arow_off + i * 32 * FK + so]);
+#pragma unroll
+            for (int j = 0; j < TT; ++j) bv[j] = ctn_ld4(&Bs[brow_off + j * 32 * FK + so]);
+            const int tf = t0 + 4 * grp;                  // first frame of the group
+            if (BWD) {
+#pragma unroll
+                for (int i = 0; i < TT; ++i) {
+                    const f32x4 y = ctn_ld4(&A2s[arow_off + i * 32 * FK + so]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = ctn_prelu(y[e], a_alpha);
+                        const float du = ag[i] * av[i][e] * arstd + ac1 + (u - amean) * ac2;
+                        const bool valid = rv[i] && (!TAIL || tf + e < t_end);
+                        av[i][e] = valid ? (y[e] > 0.f ? du : a_alpha * du) : 0.f;
+                        if (do_dalpha && valid && !(y[e] > 0.f)) dalpha += du * y[e];
+                    }
+                }
+            } else if (TAIL) {
+#pragma unroll
+                for (int i = 0; i < TT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!(tf + e < t_end)) av[i][e] = 0.f;
+            }
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < TT; ++i) rowsum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
+            }
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                if (BXF & CTN_XF_PRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[j][e] = ctn_prelu(bv[j][e], b_alpha);
+                }
+                if (BXF & CTN_XF_NORM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[j][e] = (bv[j][e] - bmean) * brstd * bg[j] + bb[j];
+                }
+                if (TAIL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!(tf + e < t_end)) bv[j][e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nk > 0) issue(t_begin, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // every wave's pieces of tile kt must have landed before any wave reads the tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int t0 = t_begin + kt * FK;
+        if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
+        const float* As = lds + (kt & 1) * BUF;
+        if (t0 + FK > t_end)
+            compute(As, t0, std::true_type{});
+        else
+            compute(As, t0, std::false_type{});
+    }
+
+    // partial tile -> C
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int n = n_blk + wn0 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_blk + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M && n < N) {
+                    float* p = (m < M1) ? a.C + (int64_t)m * a.ldc + n : a.C2 + (int64_t)(m - M1) * a.ldc2 + n;
+                    atomicAdd(p, acc[i][j][r]);
+                }
+            }
+        }
+
+    if (do_rowsum) {   // the two half-waves hold the two halves of a row's frames
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            float sv = rowsum[i];
+            sv += __shfl_xor(sv, 32);
+            const int m = m_blk + wm0 + i * 32 + l31;
+            if (half == 0 && m < M) {
+                if (m < M1) {
+                    if (a.a_rowsum) atomicAdd(a.a_rowsum + m, sv);
+                } else if (a.a_rowsum2) {
+                    atomicAdd(a.a_rowsum2 + (m - M1), sv);
+                }
+            }
+        }
+    }
+    if (BWD && a.a_dalpha != nullptr && tile_n == 0) {
+        float v[1] = {do_dalpha ? dalpha : 0.f};
+        const float tot = ctn_block_sum<1>(v, red);
+        if (tid == 0) atomicAdd(a.a_dalpha + ctn_slot(), (double)tot);
+    }
+}
+
+bool fast_ok(const ctn_gemm_nt_args& a) {
+    if (a.M < 16 || a.N < 16) return false;
+    if (a.M % 16 != 0 || a.N % 16 != 0 || a.M1 % 16 != 0) return false;
+    // k-tiles are fetched whole: rows must end on a 16-frame boundary so that the last tile stays inside the buffer
+    if (a.M1 > 0 && a.lda % 16 != 0) return false;
+    if (a.M1 < a.M && a.ldab % 16 != 0) return false;
+    if (a.ldb % 16 != 0) return false;
+    const int64_t lim = 0x40000000 / 4 - 4096;
+    if ((int64_t)a.M * a.lda >= lim || (int64_t)a.M * a.ldab >= lim || (int64_t)a.N * a.ldb >= lim) return false;
+    if (a.aflags & CTN_XF_NORMBWD) {
+        if (a.a_sst != 0 || a.lda2 % 16 != 0 || (int64_t)a.M * a.lda2 >= lim) return false;
+    }
+    if ((a.bflags & CTN_XF_NORM) && a.b_sst != 0) return false;
+    return true;
+}
+
+template <int TILE, bool BWD, int BXF>
+void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
+    const int tiles_m = ctn_cdiv(a.M, TILE), tiles_n = ctn_cdiv(a.N, TILE);
+    const int nchunks = ctn_cdiv(a.T, a.kchunk);
+    const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
+    const size_t shmem = (size_t)2 * TILE * FK * (BWD ? 3 : 2) * sizeof(float);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<TILE, BWD, BXF>), dim3(total), dim3(NTH), shmem, s, a, tiles_m, tiles_n,
+                       nchunks);
+}
+
+template <int TILE>
+void launch_fast_t(const ctn_gemm_nt_args& a, hipStream_t s) {
+    const int bxf = a.bflags & (CTN_XF_PRELU | CTN_XF_NORM);
+    if (a.aflags & CTN_XF_NORMBWD) {
+        if (bxf == 0) launch_fast_x<TILE, true, 0>(a, s);
+        else if (bxf == CTN_XF_PRELU) launch_fast_x<TILE, true, CTN_XF_PRELU>(a, s);
+        else if (bxf == CTN_XF_NORM) launch_fast_x<TILE, true, CTN_XF_NORM>(a, s);
+        else launch_fast_x<TILE, true, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
+    } else {
+        if (bxf == 0) launch_fast_x<TILE, false, 0>(a, s);
+        else if (bxf == CTN_XF_PRELU) launch_fast_x<TILE, false, CTN_XF_PRELU>(a, s);
+        else if (bxf == CTN_XF_NORM) launch_fast_x<TILE, false, CTN_XF_NORM>(a, s);
+        else launch_fast_x<TILE, false, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
+    }
+}
+
+// 64 x 64 tiles: every block adds its whole tile to C with atomics, whose volume (blocks x tile bytes) is what
+// limits this kernel -- 1024 blocks of 64 x 64 fill the chip with a quarter of the atomic traffic of 128 x 128.
+void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) { launch_fast_t<64>(a, s); }
+
 bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
     return p && ctn_aligned16(p) && ld % 4 == 0 && bs % 4 == 0 && ld >= T;
 }
@@ -258,7 +540,9 @@ extern "C" int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream) {
     if (a.bflags & CTN_XF_NORM)
         CTN_REQUIRE(a.b_mean && a.b_rstd && a.b_gamma && a.b_beta, "ctn_gemm_nt: NORM needs stats, gamma, beta");
     hipStream_t s = (hipStream_t)stream;
-    if (a.M > 64 && a.N > 64)
+    if (fast_ok(a))
+        launch_fast(a, s);
+    else if (a.M > 64 && a.N > 64)
         launch<128, 128, 2>(a, s);
     else if (a.M > 64)
         launch<128, 64, 2>(a, s);

@@ -201,7 +201,8 @@ def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, 
 
 
 def pick_kchunk(T, batch, tiles):
-    """Time steps per wgrad block: enough blocks to fill 256 CUs a few times over, chunks >= 256 frames."""
+    """Time steps per wgrad block: one generation of 4 blocks on each of the 256 CUs (every block ends with
+    atomic adds of its whole output tile, the cost that grows with the number of chunks), chunks >= 256 frames."""
     target_blocks = 1024
     chunks = max(1, target_blocks // max(1, batch * tiles))
     k = (T + chunks - 1) // chunks
@@ -232,7 +233,7 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
     a.a_rowsum, a.a_rowsum2, a.a_dalpha = _ptr(a_rowsum), _ptr(a_rowsum2), _ptr(a_dalpha)
     a.B, a.ldb, a.bbs = _ptr(B), B.stride(1), B.stride(0)
     a.bflags = bflags
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)      # the library's wgrad kernel works on 64 x 64 output tiles
     a.kchunk = kchunk or pick_kchunk(T, batch, tiles)
     a.b_alpha = _ptr(b_alpha)
     if b_stat is not None:

@@ -246,11 +246,12 @@ def test_gemm_nn_normbwd_epilogue_and_load(cln, gemm_path):
     torch.cuda.synchronize()
     assert_close(Y2, ref2, 1e-4, "normbwd on load")
     # the same transform inside the weight-gradient GEMM, with bias / slope reductions
-    Bm = rnd((B, 20, T), 46)
-    dW = torch.zeros(H, 20, device=dev())
+    NB = 20 if gemm_path == "generic" else 80
+    Bm = rnd((B, NB, T), 46)
+    dW = torch.zeros(H, NB, device=dev())
     db = torch.zeros(H, device=dev())
     da = torch.zeros(ops._lib.STAT_SLOTS, device=dev(), dtype=torch.float64)
-    ops.gemm_nt(H, 20, T, B, Y, act(Bm), dW, 20, aflags=ops.XF_NORMBWD, A2=act(y), a_alpha=f(alpha), a_stat=st,
+    ops.gemm_nt(H, NB, T, B, Y, act(Bm), dW, NB, aflags=ops.XF_NORMBWD, A2=act(y), a_alpha=f(alpha), a_stat=st,
                 a_gamma=f(gamma), a_rowsum=db, a_dalpha=da, kchunk=64)
     torch.cuda.synchronize()
     assert_close(dW, torch.einsum("bmt,bnt->mn", dy_ref, Bm), 1e-4, "wgrad normbwd")
@@ -261,7 +262,8 @@ def test_gemm_nn_normbwd_epilogue_and_load(cln, gemm_path):
 
 
 @pytest.mark.parametrize("M,N,T,batch,kchunk", [(40, 24, 301, 2, 64), (128, 128, 515, 2, 256), (200, 72, 1000, 1, 512),
-                                                (512, 128, 3999, 1, None)])
+                                                (512, 128, 3999, 1, None), (144, 128, 301, 2, 64),
+                                                (128, 256, 1021, 3, 256)])
 def test_gemm_nt_plain(M, N, T, batch, kchunk):
     from speech_amd import ops
     A, Bm = rnd((batch, M, T), 50), rnd((batch, N, T), 51)
@@ -274,9 +276,10 @@ def test_gemm_nt_plain(M, N, T, batch, kchunk):
     assert_close(rs, A.sum((0, 2)), TOL, "rowsum")
 
 
-def test_gemm_nt_split_rows_norm_b():
+@pytest.mark.parametrize("fast", [False, True])
+def test_gemm_nt_split_rows_norm_b(fast):
     from speech_amd import ops
-    M1, M2, N, T, B = 16, 24, 40, 301, 2
+    M1, M2, N, T, B = (80, 64, 128, 301, 2) if fast else (16, 24, 40, 301, 2)   # fast: the LDS-DMA kernel's shapes
     f = lambda t: t.float().to(dev())
     A1, A2 = rnd((B, M1, T), 52), rnd((B, M2, T), 53)
     y = rnd((B, N, T), 54) + 0.1

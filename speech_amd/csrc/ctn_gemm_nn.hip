@@ -396,8 +396,25 @@ __global__ __launch_bounds__(NTH) void gemm_nn_kernel(const ctn_gemm_nn_args a, 
 // ================================================================================================
 constexpr int FBM = 128, FBK = 16;
 
+#ifdef CTN_DBG_STAMPS
+// Diagnostic build only: wave 0 of every block records shader-clock stamps of its phases.
+__device__ unsigned long long g_stamps[8192 * 8];
+#define CTN_STAMP(i)                                                                       \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 8192)                                         \
+            g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();                 \
+    } while (0)
+extern "C" int ctn_debug_read_stamps(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8192 * 8);
+}
+#else
+#define CTN_STAMP(i)
+#endif
+
+// 4 blocks (waves per SIMD) per CU for both widths: 128 unified registers per lane, so that a launch of
+// 1024 x k blocks runs in whole generations.
 template <int FBN_, int XF, bool BWD>
-__global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
     // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -409,6 +426,15 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
     constexpr int XPW = (FBK / XRP) / 4;                  // X pieces per wave
     __shared__ float red[2 * (NTH / 64)];
 
+    CTN_STAMP(0);
+#ifdef CTN_DBG_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_stamps[blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int total = gridDim.x, hb = blockIdx.x;
     const int q8 = total >> 3, rr = total & 7, xcd = hb & 7;
     const int lb = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (hb >> 3);
@@ -522,11 +548,15 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     issue(0, 0);
+    CTN_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
         // Every wave's pieces of tile kt must have landed before ANY wave reads the tile: drain this wave's
         // LDS-DMA loads explicitly, the compiler does not always put the vmcnt wait ahead of the barrier.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();          // tile kt is complete; buffer (kt+1)&1 is free
+#ifdef CTN_DBG_STAMPS
+        if (kt == 0) CTN_STAMP(2);
+#endif
 #ifndef CTN_DBG_NO_LOADS
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
 #endif
@@ -573,7 +603,9 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
 #endif
         }
     }
+    CTN_STAMP(3);
     __syncthreads();              // every wave is done with the tiles: reuse them as epilogue staging
+    CTN_STAMP(4);
 #ifdef CTN_DBG_NO_EPILOGUE
     {
         float keep = 0.f;
@@ -712,6 +744,7 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
             s2 = cs2[0] + cs2[1] + cs2[2] + cs2[3];
         }
     }
+    CTN_STAMP(5);
     const bool sums = (emode == CTN_EPI_PRELUBWD) || (want_stats && a.esums != nullptr);
     if (sums) {
         float v[2] = {s1, s2};
@@ -722,6 +755,7 @@ __global__ __launch_bounds__(NTH) void gemm_nn_fast_kernel(const ctn_gemm_nn_arg
             atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
         }
     }
+    CTN_STAMP(6);
 }
 
 bool fast_ok(const ctn_gemm_nn_args& a) {
@@ -745,17 +779,28 @@ bool fast_ok(const ctn_gemm_nn_args& a) {
     return true;
 }
 
-// Tile width: ctn_gemm_nn_set_tile() or CTN_GEMM_FBN=64|128 forces one (tuning aids); otherwise the narrow tile
-// unless the launch has so many 128-wide tiles that generations of blocks overlap anyway.
+// Tile width: ctn_gemm_nn_set_tile() or CTN_GEMM_FBN=64|128 forces one (tuning aids).  Otherwise the width whose
+// blocks fill whole generations of the chip's 4-blocks-per-CU slots best (all blocks of a launch take the same
+// time, so a partly filled last generation is pure tail); the wide tile wins ties, it re-reads less.
 int g_forced_fbn = -1;
-int pick_fbn(int64_t tiles128) {
+int pick_fbn(const ctn_gemm_nn_args& a) {
     if (g_forced_fbn < 0) {
         const char* e = getenv("CTN_GEMM_FBN");
         const int v = e ? atoi(e) : 0;
         g_forced_fbn = (v == 64 || v == 128) ? v : 0;
     }
     if (g_forced_fbn) return g_forced_fbn;
-    return tiles128 >= 8192 ? 128 : 64;
+    static const int slots = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return 4 * cus;
+    }();
+    auto fill = [](int64_t blocks) { return (double)blocks / (double)((blocks + slots - 1) / slots * slots); };
+    const int64_t rows = (int64_t)ctn_cdiv(a.M, FBM) * a.batch;
+    const double f128 = fill(rows * ctn_cdiv(a.T, 128)), f64 = fill(rows * ctn_cdiv(a.T, 64));
+    return f128 >= f64 - 0.02 ? 128 : 64;
 }
 
 template <int FBN_>
@@ -797,8 +842,7 @@ int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
 }
 
 int launch_fast(const ctn_gemm_nn_args& a, hipStream_t s) {
-    const int64_t tiles128 = (int64_t)ctn_cdiv(a.M, FBM) * ctn_cdiv(a.T, 128) * a.batch;
-    return pick_fbn(tiles128) == 128 ? launch_fast_n<128>(a, s) : launch_fast_n<64>(a, s);
+    return pick_fbn(a) == 128 ? launch_fast_n<128>(a, s) : launch_fast_n<64>(a, s);
 }
 
 template <int BM, int WAVES_M>

@@ -21,6 +21,20 @@ from .ops import (XF_PRELU, XF_NORM, XF_NORMBWD, EPI_STORE, EPI_STATS, EPI_HEADS
 
 
 # ------------------------------------------------------------------------------------------------ helpers
+FLAT_ALIGN = 64      # floats: every tensor of a flat parameter / gradient buffer starts on a 256-byte boundary
+
+
+def flat_layout(params):
+    """Offsets (in floats) of `params` inside a flat buffer and the buffer's length.  Scalars (PReLU slopes)
+    would otherwise leave every following weight matrix 4-byte aligned only, which takes the GEMMs that read
+    weights or write weight gradients in place off their 16-byte paths."""
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+    return offsets, off
+
+
 class GradSink:
     """Zeroed gradient buffers for a list of parameters (one flat allocation, views per parameter).
 
@@ -30,18 +44,14 @@ class GradSink:
     def __init__(self, params, flat=None):
         self.params = list(params)
         dev = self.params[0].device
-        sizes = [p.numel() for p in self.params]
+        self.offsets, total = flat_layout(self.params)
         if flat is None:
-            self.flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+            self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         else:                                  # caller-owned buffer (e.g. the trainer's all-reduce bucket)
-            assert flat.numel() == sum(sizes) and flat.dtype == torch.float32 and flat.is_contiguous()
+            assert flat.numel() == total and flat.dtype == torch.float32 and flat.is_contiguous()
             self.flat = flat
             self.flat.zero_()
-        self.views, self.offsets, off = [], [], 0
-        for p, n in zip(self.params, sizes):
-            self.views.append(self.flat[off:off + n].view(p.shape))
-            self.offsets.append(off)
-            off += n
+        self.views = [self.flat[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._alpha = []
         self.dalpha = None

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .functional import ConvTasNetFn
+from .functional import ConvTasNetFn, flat_layout
 
 
 def allreduce_flat(flat, n_buckets=1, group=None):
@@ -57,15 +57,13 @@ class FlatTrainer:
         dev = params[0].device
         if dev.type != "cuda":
             raise ops._lib.CtnError("FlatTrainer needs the model on a GPU")
-        sizes = [p.numel() for p in params]
-        self.flat_p = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
-        off = 0
+        offsets, total = flat_layout(params)       # the gradient sink lays its buffer out the same way
+        self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         with torch.no_grad():
-            for p, n in zip(params, sizes):
-                view = self.flat_p[off:off + n].view(p.shape)
+            for p, off in zip(params, offsets):
+                view = self.flat_p[off:off + p.numel()].view(p.shape)
                 view.copy_(p)
                 p.data = view                      # parameters become views of the flat buffer
-                off += n
         self.params = params
         self.flat_g = torch.zeros_like(self.flat_p)
         self.m = torch.zeros_like(self.flat_p)

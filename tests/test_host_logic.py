@@ -170,3 +170,17 @@ def test_encoder_geometry():
     assert _enc_geometry(32000, 16, 8) == (0, 0, 3999)
     assert _enc_geometry(8003, 16, 8) == (5, 2, 1000)
     assert _enc_geometry(64000, 2, 1) == (0, 0, 63999)
+
+
+def test_flat_layout_is_aligned_and_disjoint():
+    """Every tensor of the flat parameter / gradient buffers starts on a 256-byte boundary (scalars must not
+    push the weight matrices off the GEMMs' 16-byte paths) and no two tensors overlap."""
+    import torch
+    from speech_amd.functional import flat_layout, FLAT_ALIGN
+    params = [torch.zeros(s) for s in [(512, 128, 1), (1,), (512,), (1,), (3, 7), (128, 512, 1)]]
+    offsets, total = flat_layout(params)
+    end = 0
+    for p, off in zip(params, offsets):
+        assert off % FLAT_ALIGN == 0 and off >= end
+        end = off + p.numel()
+    assert total >= end and total % FLAT_ALIGN == 0

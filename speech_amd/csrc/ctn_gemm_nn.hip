@@ -425,6 +425,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int XRP = 64 / XLPR;                        // X-tile rows per piece
     constexpr int XPW = (FBK / XRP) / 4;                  // X pieces per wave
     __shared__ float red[2 * (NTH / 64)];
+    __shared__ float rowc[2][FBM];
 
     CTN_STAMP(0);
 #ifdef CTN_DBG_STAMPS
@@ -459,6 +460,20 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             Gs[k] = k < K ? a.gamma[k] : 0.f;
             Bes[k] = (!BWD && k < K) ? a.beta[k] : 0.f;
         }
+    }
+    if (tid < FBM) {              // epilogue row constants of this tile: bias and (NORMBWD epilogue) gamma
+        const int m = m_blk + tid;
+        float bv_ = 0.f, gv_ = 0.f;
+        if (m < M) {
+            if (a.emode == CTN_EPI_HEADS && m >= a.Mo) {
+                if (a.bias2) bv_ = a.bias2[m - a.Mo];
+            } else if (a.bias) {
+                bv_ = a.bias[m];
+            }
+            if (a.emode == CTN_EPI_NORMBWD) gv_ = a.egamma[m];
+        }
+        rowc[0][tid] = bv_;
+        rowc[1][tid] = gv_;
     }
     // per-frame statistics of this lane's columns
     float mean[NJ], rstd[NJ], c1[NJ], c2[NJ];
@@ -641,85 +656,100 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float s1 = 0.f, s2 = 0.f;
     float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
     const bool want_stats = (emode == CTN_EPI_STATS || emode == CTN_EPI_NORMBWD);
+    // Row constants come from LDS (rowc, filled in the prologue) and the optional per-element input (residual,
+    // accumulate target or pre-activation) is fetched 4 rows ahead with unconditional loads: a load inside the
+    // row loop would put a full vmcnt wait -- which also waits for the stores before it -- in front of every store.
+    constexpr int NQ = 64 / RS;
+    const int split = (emode == CTN_EPI_HEADS) ? a.Mo : M;          // rows >= split go to Y2
+    const float* lo_base = a.Y; int64_t lo_ld = a.ldy, lo_bs = a.ybs; bool lo_use = false;
+    const float* hi_base = a.Y; int64_t hi_ld = a.ldy, hi_bs = a.ybs; bool hi_use = false;
+    if ((emode == CTN_EPI_HEADS || emode == CTN_EPI_ADD) && a.R) {
+        lo_base = a.R; lo_ld = a.ldr; lo_bs = a.rbs; lo_use = true;
+    } else if (emode == CTN_EPI_PRELUBWD || emode == CTN_EPI_NORMBWD) {
+        lo_base = a.E; lo_ld = a.lde; lo_bs = a.ebs; lo_use = true;
+    }
+    if (emode == CTN_EPI_HEADS && a.accumulate && split < M) {
+        hi_base = a.Y2; hi_ld = a.ldy2; hi_bs = a.y2bs; hi_use = true;
+    }
+    const bool has_aux = lo_use || hi_use;
+    const int tl = min(t, (int)a.ldy - 4);                          // clamped column for the unconditional loads
+    auto aux_ptr = [&](int m) {
+        const int mc = min(m, M - 1);
+        return mc < split ? lo_base + (int64_t)b * lo_bs + (int64_t)mc * lo_ld + tl
+                          : hi_base + (int64_t)b * hi_bs + (int64_t)(mc - split) * hi_ld + tl;
+    };
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        if ((wave >> 1) == pass) {
+        // every wave stages its MFMA row tile `pass` (staging rows 0..31: tile rows 32 pass .. of the upper wave
+        // pair, 32..63: of the lower pair), so half of each wave's accumulators are dead from here on
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + j * 32 + l31] = acc[i][j][r];
-        }
+            for (int r = 0; r < 16; ++r)
+                stg[((wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + j * 32 + l31] = acc[pass][j][r];
         __syncthreads();
-        if (col_ok) {
+        auto tile_row = [&](int srow) { return (srow >> 5) * 64 + pass * 32 + (srow & 31); };
+        f32x4 aux[4];
 #pragma unroll
-            for (int q = 0; q < 64 / RS; ++q) {
-                const int row = r0 + RS * q;
-                const int m = m_blk + pass * 64 + row;
-                if (m >= M) continue;
-                f32x4 v = ctn_ld4(&stg[row * FBN_ + c4]);
-                if (emode == CTN_EPI_HEADS) {
-                    if (m < a.Mo) {
-                        const float bsv = a.bias ? a.bias[m] : 0.f;
-                        if (a.R) {
-                            const f32x4 rv = ctn_ld4(a.R + (int64_t)b * a.rbs + (int64_t)m * a.ldr + t);
-                            v += rv;
-                        }
-                        v += bsv;
-                        ctn_st4(a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t, v);
-                    } else {
-                        const int m2 = m - a.Mo;
-                        const float bsv = a.bias2 ? a.bias2[m2] : 0.f;
-                        float* p = a.Y2 + (int64_t)b * a.y2bs + (int64_t)m2 * a.ldy2 + t;
-                        if (a.accumulate) v += ctn_ld4(p);
-                        v += bsv;
-                        ctn_st4(p, v);
-                    }
-                } else if (emode == CTN_EPI_PRELUBWD || emode == CTN_EPI_NORMBWD) {
-                    const f32x4 ev = ctn_ld4(a.E + (int64_t)b * a.ebs + (int64_t)m * a.lde + t);
-                    if (emode == CTN_EPI_NORMBWD) {
-                        const float gmv = a.egamma[m];
+        for (int q = 0; q < 4; ++q) aux[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_aux) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (t + e < T) {
-                                const float xh = (ctn_prelu(ev[e], ea) - em[e]) * er[e];
-                                const float g = gmv * v[e];
-                                cs1[e] += g;
-                                cs2[e] += g * xh;
-                            }
-                        }
-                    } else {
+            for (int q = 0; q < (NQ < 4 ? NQ : 4); ++q) aux[q] = ctn_ld4(aux_ptr(m_blk + tile_row(r0 + RS * q)));
+        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (!(ev[e] > 0.f)) {
-                                if (t + e < T) s1 += v[e] * ev[e];
-                                v[e] *= ea;
-                            }
+        for (int q = 0; q < NQ; ++q) {
+            const int row = r0 + RS * q;
+            const int trow = tile_row(row);
+            const int m = m_blk + trow;
+            const bool ok = col_ok && m < M;
+            const bool lower = m < split;
+            f32x4 v = ctn_ld4(&stg[row * FBN_ + c4]);
+            f32x4 x = aux[q & 3];
+            if (has_aux && q + 4 < NQ) aux[q & 3] = ctn_ld4(aux_ptr(m_blk + tile_row(r0 + RS * (q + 4))));
+            if (!(lower ? lo_use : hi_use)) x = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float bsv = rowc[0][trow];
+            float* op = lower ? a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t
+                              : a.Y2 + (int64_t)b * a.y2bs + (int64_t)(m - split) * a.ldy2 + t;
+            if (emode == CTN_EPI_PRELUBWD || emode == CTN_EPI_NORMBWD) {
+                if (emode == CTN_EPI_NORMBWD) {
+                    const float gmv = rowc[1][trow];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (ok && t + e < T) {
+                            const float xh = (ctn_prelu(x[e], ea) - em[e]) * er[e];
+                            const float g = gmv * v[e];
+                            cs1[e] += g;
+                            cs2[e] += g * xh;
                         }
                     }
-                    ctn_st4(a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t, v);
                 } else {
-                    v += a.bias ? a.bias[m] : 0.f;
-                    if (emode == CTN_EPI_ADD && a.R) v += ctn_ld4(a.R + (int64_t)b * a.rbs + (int64_t)m * a.ldr + t);
-                    if (emode == CTN_EPI_SIGMOID) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + expf(-v[e]));
+                    for (int e = 0; e < 4; ++e) {
+                        if (!(x[e] > 0.f)) {
+                            if (ok && t + e < T) s1 += v[e] * x[e];
+                            v[e] *= ea;
+                        }
                     }
-                    ctn_st4(a.Y + (int64_t)b * a.ybs + (int64_t)m * a.ldy + t, v);
-                    if (emode == CTN_EPI_STATS) {
+                }
+            } else {
+                v += x;
+                v += bsv;
+                if (emode == CTN_EPI_SIGMOID) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (t + e < T) {
-                                const float u = ctn_prelu(v[e], ea);
-                                cs1[e] += u;
-                                cs2[e] += u * u;
-                            }
+                    for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + expf(-v[e]));
+                }
+                if (emode == CTN_EPI_STATS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (ok && t + e < T) {
+                            const float u = ctn_prelu(v[e], ea);
+                            cs1[e] += u;
+                            cs2[e] += u * u;
                         }
                     }
                 }
             }
+            if (ok) ctn_st4(op, v);
         }
         __syncthreads();
     }

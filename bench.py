@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--streams", type=int, default=1, help="sub-batches of a rank's shard run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -133,7 +134,7 @@ def main():
 
     cfg = PAPER
     model = build_model(cfg, device)
-    trainer = FlatTrainer(model, PIT1d(NegSISDR(), cfg["n_sources"]), lr=1e-3, max_norm=5.0)
+    trainer = FlatTrainer(model, PIT1d(NegSISDR(), cfg["n_sources"]), lr=1e-3, max_norm=5.0, n_streams=args.streams)
     n_batches = 4
     batches = []
     for i in range(n_batches):

@@ -349,6 +349,132 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward, gLN rows
+// The separator's hot case as straight-line code: per-batch statistics (gLN), output-side norm/PReLU backward,
+// input-side PReLU + norm, one block per (batch, channel) row that fits 4 float4 per thread.  Every global load
+// of the row is issued before anything is consumed (unconditional, clamped addresses, validity by selects):
+// the general kernel above guards its loads and statistics fetches, which the compiler turns into branches
+// with full vmcnt waits.
+constexpr int GIT = 4;                 // float4 per thread: rows of up to 4 * 256 * 4 = 4096 frames
+template <int P>
+__global__ __launch_bounds__(NTH) void dw_bwd_gln_kernel(const ctn_dw_bwd_args a, const int lw, const int H4) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NV = 8 + P;
+    __shared__ float red[NV * (NTH / 64)];
+    float* D = lds;
+    float* Xh = lds + lw;
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int T = a.T, d = a.dilation, padL = a.pad_left;
+    const int tid = threadIdx.x;
+    const int ldmin = (int)min(min(a.lddn2, a.ldy2), a.ldx);      // every row holds at least this many floats
+    const float* dnrow = a.dn2 + (int64_t)b * a.dn2bs + (int64_t)c * a.lddn2;
+    const float* y2row = a.y2 + (int64_t)b * a.y2bs + (int64_t)c * a.ldy2;
+    const float* xrow = a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx;
+    f32x4 vdn[GIT], vy[GIT], vx[GIT];
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) {
+        const int tq = min(4 * (tid + j * NTH), ldmin - 4);
+        vdn[j] = ctn_ld4(dnrow + tq);
+        vy[j] = ctn_ld4(y2row + tq);
+        vx[j] = ctn_ld4(xrow + tq);
+    }
+    const float a1 = a.alpha1[0], a2 = a.alpha2[0];
+    const float m2 = a.mean2[(int64_t)b * a.ssb2], r2 = a.rstd2[(int64_t)b * a.ssb2];
+    const float k1 = a.c1_2[(int64_t)b * a.ssb2], k2 = a.c2_2[(int64_t)b * a.ssb2];
+    const float m1 = a.mean1[(int64_t)b * a.ssb1], r1 = a.rstd1[(int64_t)b * a.ssb1];
+    const float g2 = a.gamma2[c], g1 = a.gamma1[c], be1 = a.beta1[c];
+    float w[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) w[k] = a.w[(int64_t)c * P + k];
+    // zero halos: [0, H4) and [H4 + 4 * GIT * NTH ... ) are covered by clearing everything outside the row slots
+    for (int i = tid; i < H4 / 4; i += NTH) {
+        ctn_st4(&D[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+        ctn_st4(&Xh[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    for (int i = H4 / 4 + GIT * NTH + tid; i < lw / 4; i += NTH) {
+        ctn_st4(&D[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+        ctn_st4(&Xh[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    float dgamma2 = 0.f, dbeta2 = 0.f, dbias = 0.f, dalpha2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) {
+        const int t = 4 * (tid + j * NTH);
+        f32x4 dv, xv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = t + e < T;
+            const float dn = vdn[j][e], y2 = vy[j][e];
+            const float u = ctn_prelu(y2, a2);
+            const float xc = u - m2;
+            const float du = g2 * dn * r2 + k1 + xc * k2;
+            const float dy = y2 > 0.f ? du : a2 * du;
+            dgamma2 += valid ? dn * xc * r2 : 0.f;
+            dbeta2 += valid ? dn : 0.f;
+            dalpha2 += (valid && !(y2 > 0.f)) ? du * y2 : 0.f;
+            dbias += valid ? dy : 0.f;
+            dv[e] = valid ? dy : 0.f;
+            const float xh = (ctn_prelu(vx[j][e], a1) - m1) * r1;
+            xv[e] = valid ? xh : 0.f;
+        }
+        ctn_st4(&D[H4 + t], dv);
+        ctn_st4(&Xh[H4 + t], xv);
+    }
+    __syncthreads();
+    float dwa[P], dwb[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) dwa[k] = dwb[k] = 0.f;
+    float dgamma1 = 0.f, dbeta1 = 0.f, s1 = 0.f, s2 = 0.f;
+    float* dxrow = a.dx + (int64_t)b * a.dxbs + (int64_t)c * a.lddx;
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) {
+        const int t = 4 * (tid + j * NTH);
+        if (t < T) {
+            const int i0 = H4 + t;
+            const f32x4 dy4 = ctn_ld4(&D[i0]);
+            const f32x4 xh4 = ctn_ld4(&Xh[i0]);
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const f32x4 dk = lds_read4(D, i0 - k * d + padL);
+                const f32x4 xk = lds_read4(Xh, i0 + k * d - padL);
+                o += w[k] * dk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ti = t + e + k * d - padL;
+                    dwa[k] += dy4[e] * xk[e];
+                    dwb[k] += (ti >= 0 && ti < T) ? dy4[e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (t + e < T) {
+                    const float g = g1 * o[e];
+                    dgamma1 += o[e] * xh4[e];
+                    dbeta1 += o[e];
+                    s1 += g;
+                    s2 += g * xh4[e];
+                }
+            }
+            ctn_st4(dxrow + t, o);
+        }
+    }
+    float v[NV];
+    v[0] = dgamma2; v[1] = dbeta2; v[2] = dbias; v[3] = dgamma1; v[4] = dbeta1;
+    v[5] = dalpha2; v[6] = s1; v[7] = s2;
+#pragma unroll
+    for (int k = 0; k < P; ++k) v[8 + k] = g1 * dwa[k] + be1 * dwb[k];
+    const float tot = ctn_block_sum<NV>(v, red);
+    if (tid == 0 && a.dgamma2) atomicAdd(a.dgamma2 + c, tot);
+    if (tid == 1 && a.dbeta2) atomicAdd(a.dbeta2 + c, tot);
+    if (tid == 2 && a.dbias) atomicAdd(a.dbias + c, tot);
+    if (tid == 3 && a.dgamma1) atomicAdd(a.dgamma1 + c, tot);
+    if (tid == 4 && a.dbeta1) atomicAdd(a.dbeta1 + c, tot);
+    if (tid == 5 && a.dalpha2) atomicAdd(a.dalpha2 + ctn_slot(), (double)tot);
+    if ((tid == 6 || tid == 7) && a.isums)
+        atomicAdd(a.isums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + (tid - 6), (double)tot);
+    if (tid >= 8 && tid < 8 + P) atomicAdd(a.dw + (int64_t)c * P + (tid - 8), tot);
+}
+
 bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
     return p && ctn_aligned16(p) && ld % 4 == 0 && bs % 4 == 0 && ld >= T;
 }
@@ -405,12 +531,30 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
     if (a.cln) CTN_REQUIRE(!a.icol || a.icol_ld >= a.T, "ctn_dw_bwd: icol_ld < T");
     const int padR = (a.P - 1) * a.dilation - a.pad_left;
     const int H = a.pad_left > padR ? a.pad_left : padR;
+    hipStream_t s = (hipStream_t)stream;
+    {   // whole-row gLN kernel: the separator's configuration
+        const bool full = (a.oflags & CTN_XF_NORMBWD) && (a.xflags & CTN_XF_NORM) && (a.xflags & CTN_XF_PRELU) &&
+                          a.alpha1 && a.alpha2 && !a.cln && a.sst1 == 0 && a.sst2 == 0;
+        const int H4 = (H + 3) & ~3;
+        const int lwg = H4 + 4 * GIT * NTH + H4 + 8;
+        if (full && a.P <= 4 && a.T <= 4 * GIT * NTH && (size_t)lwg * 8 <= 60 * 1024 && a.T >= 4) {
+            dim3 grid(a.C, a.batch);
+            const size_t shm = (size_t)lwg * 8;
+            switch (a.P) {
+                case 1: hipLaunchKernelGGL(dw_bwd_gln_kernel<1>, grid, dim3(NTH), shm, s, a, lwg, H4); break;
+                case 2: hipLaunchKernelGGL(dw_bwd_gln_kernel<2>, grid, dim3(NTH), shm, s, a, lwg, H4); break;
+                case 3: hipLaunchKernelGGL(dw_bwd_gln_kernel<3>, grid, dim3(NTH), shm, s, a, lwg, H4); break;
+                default: hipLaunchKernelGGL(dw_bwd_gln_kernel<4>, grid, dim3(NTH), shm, s, a, lwg, H4); break;
+            }
+            CTN_CHECK_LAUNCH("ctn_dw_bwd");
+            return CTN_OK;
+        }
+    }
     int CG, TT, lw;
     pick_tile(a.T, 2 * H, a.cln != 0, 2, &CG, &TT, &lw);
     CTN_REQUIRE((size_t)lw * 8 <= 64 * 1024, "ctn_dw_bwd: dilation halo too large for LDS");
     dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
     const size_t shmem = (size_t)lw * 8;
-    hipStream_t s = (hipStream_t)stream;
 #define CTN_DW_BWD_CASE(PP) \
     case PP: hipLaunchKernelGGL(dw_bwd_kernel<PP>, grid, dim3(NTH), shmem, s, a, CG, TT, lw, H); break;
     switch (a.P) {

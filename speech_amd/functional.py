@@ -41,7 +41,7 @@ class GradSink:
     PReLU slopes are reduced in fp64 by the kernels; their slots live in `dalpha` and are folded
     into the fp32 views by finish()."""
 
-    def __init__(self, params, flat=None):
+    def __init__(self, params, flat=None, zero=True):
         self.params = list(params)
         dev = self.params[0].device
         self.offsets, total = flat_layout(self.params)
@@ -50,7 +50,8 @@ class GradSink:
         else:                                  # caller-owned buffer (e.g. the trainer's all-reduce bucket)
             assert flat.numel() == total and flat.dtype == torch.float32 and flat.is_contiguous()
             self.flat = flat
-            self.flat.zero_()
+            if zero:                           # zero=False: the caller zeroed it and several sinks add into it
+                self.flat.zero_()
         self.views = [self.flat[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._alpha = []
@@ -74,7 +75,7 @@ class GradSink:
             dev = self.flat.device
             src = torch.tensor(idx, device=dev, dtype=torch.long)
             dst = torch.tensor([self.offsets[i] for i in idx], device=dev, dtype=torch.long)
-            self.flat.index_copy_(0, dst, self.dalpha.index_select(0, src).sum(dim=1).float())
+            self.flat.index_add_(0, dst, self.dalpha.index_select(0, src).sum(dim=1).float())
         return self.views
 
 
@@ -494,7 +495,7 @@ class ConvTasNetFn(torch.autograd.Function):
         B, N, Tf = w.shape
         L, S, n_src, eps = cfg["kernel_size"], cfg["stride"], cfg["n_sources"], cfg["eps"]
         dev = w.device
-        sink = GradSink(mp.tensors, cfg.get("grad_flat"))
+        sink = GradSink(mp.tensors, cfg.get("grad_flat"), cfg.get("grad_zero", True))
         dout = dout.contiguous().float()
         dz = new_act(B, n_src * N, Tf, dev)
         dw_dec = new_act(B, N, Tf, dev)
@@ -504,6 +505,8 @@ class ConvTasNetFn(torch.autograd.Function):
         ops.encoder_bwd(x2, pad_left, N, L, S, relu, w, sink.g(mp.enc_W).view(N, L), dw_a=dw_dec, dn=dn0, stat=st0,
                         gamma=mp.g0.detach().view(-1), dgamma=sink.g(mp.g0).view(-1), dbeta=sink.g(mp.be0).view(-1))
         grads = sink.finish()
+        if cfg.get("grad_detached"):           # the caller reads its flat buffer; autograd must not add views of it
+            return (None, None) + (None,) * len(grads)
         return (None, None) + tuple(grads)
 
 

@@ -42,12 +42,18 @@ def shard_batch(mixture, sources, rank, world):
 
 class FlatTrainer:
     def __init__(self, model, criterion, lr=1e-3, max_norm=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 n_buckets=1):
+                 n_buckets=1, n_streams=1):
         self.model, self.criterion = model, criterion
         self.lr, self.max_norm, self.betas, self.eps = lr, max_norm, betas, eps
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.n_buckets = max(1, n_buckets)
+        # n_streams > 1: the rank's shard is cut into that many sub-batches whose forward/backward passes run on
+        # separate HIP streams.  Every kernel launch of one pass fills the chip with blocks that move through
+        # their load, MFMA and store phases in lockstep; two passes in flight put one's stores beside the
+        # other's MFMAs.  The result is the same sum of per-utterance gradients (order of additions aside).
+        self.n_streams = max(1, n_streams)
+        self.streams = None
         if not model._fused_ok():
             raise NotImplementedError("FlatTrainer drives the fused Conv-TasNet schedule only")
         params = model.fused_parameters()
@@ -74,15 +80,43 @@ class FlatTrainer:
             dist.broadcast(self.flat_p, src=0, group=self.group)
 
     def forward_backward(self, mixture, sources):
-        """Fills self.flat_g with this rank's gradient of the shard-mean loss; returns (loss, perm)."""
-        cfg = self.model.fused_config()
-        cfg["grad_flat"] = self.flat_g
-        out = ConvTasNetFn.apply(mixture, cfg, *self.params)
-        loss, perm = self.criterion(out, sources)
+        """Fills self.flat_g with this rank's gradient of the shard-mean loss; returns (loss, perm).
+        The gradients live in flat_g only (parameters' .grad stay None)."""
+        B = mixture.shape[0]
+        n = min(self.n_streams, B)
         for p in self.params:
             p.grad = None
-        loss.backward()
-        return loss.detach(), perm
+        if n == 1:
+            cfg = self.model.fused_config()
+            cfg["grad_flat"], cfg["grad_detached"] = self.flat_g, True
+            out = ConvTasNetFn.apply(mixture, cfg, *self.params)
+            loss, perm = self.criterion(out, sources)
+            loss.backward()
+            return loss.detach(), perm
+        if self.streams is None:
+            self.streams = [torch.cuda.Stream(device=self.flat_p.device) for _ in range(self.n_streams)]
+        main = torch.cuda.current_stream()
+        self.flat_g.zero_()
+        bounds = [B * i // n for i in range(n + 1)]
+        losses, perms = [], []
+        for i in range(n):
+            st = self.streams[i]
+            st.wait_stream(main)                   # inputs and the zeroed gradient buffer are ready
+            mixture.record_stream(st)
+            sources.record_stream(st)
+            lo, hi = bounds[i], bounds[i + 1]
+            with torch.cuda.stream(st):
+                cfg = self.model.fused_config()
+                cfg["grad_flat"], cfg["grad_zero"], cfg["grad_detached"] = self.flat_g, False, True
+                out = ConvTasNetFn.apply(mixture[lo:hi], cfg, *self.params)
+                loss_i, perm_i = self.criterion(out, sources[lo:hi])
+                loss_i = loss_i * ((hi - lo) / B)  # mean over the sub-batch -> share of the shard mean
+                loss_i.backward()
+                losses.append(loss_i.detach())
+                perms.append(perm_i)
+        for i in range(n):
+            main.wait_stream(self.streams[i])
+        return torch.stack(losses).sum(), torch.cat(perms, dim=0)
 
     def reduce_gradients(self):
         if self.world == 1:

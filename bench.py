@@ -70,10 +70,12 @@ def instrumented_step(trainer, mixture, sources):
     ops.gemm_nt = wrap("gemm_nt", lambda M, N, T, batch, *a, **k: 2.0 * M * N * T * batch)
     ops.dw_fwd = wrap("dw_fwd", lambda x, w, bias, y, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
     ops.dw_bwd = wrap("dw_bwd", lambda dn2, x, *a, **k: 4.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
+    graph_mode, trainer.use_graph = trainer.use_graph, False     # the timed launches must run eagerly
     try:
         trainer.step(mixture, sources)
         torch.cuda.synchronize()
     finally:
+        trainer.use_graph = graph_mode
         for k, f in orig.items():
             setattr(ops, k, f)
     out = {}
@@ -110,6 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--graph", action="store_true", help="replay the forward/backward pass from a HIP graph")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches of a rank's shard run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -134,7 +137,7 @@ def main():
 
     cfg = PAPER
     model = build_model(cfg, device)
-    trainer = FlatTrainer(model, PIT1d(NegSISDR(), cfg["n_sources"]), lr=1e-3, max_norm=5.0, n_streams=args.streams)
+    trainer = FlatTrainer(model, PIT1d(NegSISDR(), cfg["n_sources"]), lr=1e-3, max_norm=5.0, n_streams=args.streams, use_graph=args.graph)
     n_batches = 4
     batches = []
     for i in range(n_batches):

@@ -69,12 +69,20 @@ class GradSink:
         self._alpha.append(i)
         return self.dalpha[i]
 
+    _index_cache = {}      # (device, slope indices, offsets) -> device index tensors; built once, so that a step
+                           # has no host-to-device copy (a synchronisation point, and not capturable in a graph)
+
     def finish(self):
         if self._alpha:
-            idx = sorted(set(self._alpha))
+            idx = tuple(sorted(set(self._alpha)))
             dev = self.flat.device
-            src = torch.tensor(idx, device=dev, dtype=torch.long)
-            dst = torch.tensor([self.offsets[i] for i in idx], device=dev, dtype=torch.long)
+            key = (str(dev), idx, tuple(self.offsets[i] for i in idx))
+            hit = GradSink._index_cache.get(key)
+            if hit is None:
+                hit = (torch.tensor(key[1], device=dev, dtype=torch.long),
+                       torch.tensor(key[2], device=dev, dtype=torch.long))
+                GradSink._index_cache[key] = hit
+            src, dst = hit
             self.flat.index_add_(0, dst, self.dalpha.index_select(0, src).sum(dim=1).float())
         return self.views
 
@@ -479,9 +487,10 @@ class ConvTasNetFn(torch.autograd.Function):
         padding, pad_left, Tf = _enc_geometry(T, L, S)
         x2 = x.detach().reshape(B, T).contiguous().float()
         w = new_act(B, N, Tf, dev)
-        acc0 = Accum(B, Tf, causal, dev)
-        ops.encoder_fwd(x2, pad_left, mp.enc_W.detach(), S, relu, w, acc0)
-        mask, saved = separator_forward(mp, w, acc0, eps)
+        with ops.zero_arena(dev, (2 * len(mp.layers) + 4) * ops.accum_bytes(B, Tf, causal)):
+            acc0 = Accum(B, Tf, causal, dev)
+            ops.encoder_fwd(x2, pad_left, mp.enc_W.detach(), S, relu, w, acc0)
+            mask, saved = separator_forward(mp, w, acc0, eps)
         out = torch.empty((B, n_src, T), device=dev, dtype=torch.float32)
         ops.maskdecode_fwd(w, mask, n_src, mp.dec_W.detach(), S, out, pad_left)
         ctx.mp, ctx.saved_acts = mp, (x2, w, mask, saved, pad_left, relu)
@@ -501,7 +510,8 @@ class ConvTasNetFn(torch.autograd.Function):
         dw_dec = new_act(B, N, Tf, dev)
         ops.maskdecode_bwd(dout, pad_left, w, mask, n_src, mp.dec_W.detach(), S, True, dz, dw_dec,
                            sink.g(mp.dec_W).view(N, L))
-        dn0, st0 = separator_backward(mp, w, saved, dz, sink, eps)
+        with ops.zero_arena(dev, (2 * len(mp.layers) + 4) * ops.accum_bytes(B, Tf, cfg["causal"])):
+            dn0, st0 = separator_backward(mp, w, saved, dz, sink, eps)
         ops.encoder_bwd(x2, pad_left, N, L, S, relu, w, sink.g(mp.enc_W).view(N, L), dw_a=dw_dec, dn=dn0, stat=st0,
                         gamma=mp.g0.detach().view(-1), dgamma=sink.g(mp.g0).view(-1), dbeta=sink.g(mp.be0).view(-1))
         grads = sink.finish()

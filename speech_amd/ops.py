@@ -68,6 +68,67 @@ class Stat:
         self.c1 = self.c2 = None
 
 
+class ZeroArena:
+    """One zero-filled allocation handed out in 256-byte aligned slices: a forward or backward pass needs about a
+    hundred small zeroed accumulators, and a fill kernel per accumulator costs more than the accumulators' users
+    save.  A slice keeps the whole allocation alive; when the arena is used up, take() returns None."""
+
+    def __init__(self, device, nbytes):
+        self.buf = torch.zeros((nbytes + 7) // 8, device=device, dtype=torch.float64)
+        self.device, self.off, self.nbytes = self.buf.device, 0, self.buf.numel() * 8
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= d
+        item = 8 if dtype == torch.float64 else 4
+        nbytes = (n * item + 255) // 256 * 256
+        if self.off + nbytes > self.nbytes:
+            return None
+        lo = self.off // 8
+        self.off += nbytes
+        flat = self.buf[lo:lo + nbytes // 8]
+        if dtype != torch.float64:
+            flat = flat.view(dtype)
+        return flat[:n].view(shape)
+
+
+_arena = None
+
+
+class zero_arena:
+    """with zero_arena(device, nbytes): zeroed accumulators created inside come from one allocation."""
+
+    def __init__(self, device, nbytes):
+        self.device, self.nbytes = device, nbytes
+
+    def __enter__(self):
+        global _arena
+        self.prev = _arena
+        _arena = ZeroArena(self.device, self.nbytes)
+        return _arena
+
+    def __exit__(self, *exc):
+        global _arena
+        _arena = self.prev
+        return False
+
+
+def zeros(shape, device, dtype):
+    """Zeroed tensor, from the active arena when there is one on this device with room left."""
+    if _arena is not None and _arena.device == torch.device(device):
+        t = _arena.take(tuple(shape), dtype)
+        if t is not None:
+            return t
+    return torch.zeros(shape, device=device, dtype=dtype)
+
+
+def accum_bytes(B, T, cln):
+    """Arena bytes of one Accum (see ZeroArena.take's rounding)."""
+    n = B * 2 * round4(T) * 4 if cln else B * _lib.STAT_SLOTS * 2 * 8
+    return (n + 255) // 256 * 256
+
+
 class Accum:
     """Zeroed accumulators for one norm's statistics: double (B, STAT_SLOTS, 2) for gLN (slot-replicated, the
     value is the sum over slots), float (B, 2, ld) for cLN."""
@@ -77,12 +138,12 @@ class Accum:
     def __init__(self, B, T, cln, device):
         if cln:
             self.ld = round4(T)
-            self.col = torch.zeros((B, 2, self.ld), device=device, dtype=torch.float32)
+            self.col = zeros((B, 2, self.ld), device, torch.float32)
             self.sums = None
         else:
             self.ld = 0
             self.col = None
-            self.sums = torch.zeros((B, _lib.STAT_SLOTS, 2), device=device, dtype=torch.float64)
+            self.sums = zeros((B, _lib.STAT_SLOTS, 2), device, torch.float64)
 
 
 # ------------------------------------------------------------------------------------------------ norms

@@ -42,7 +42,7 @@ def shard_batch(mixture, sources, rank, world):
 
 class FlatTrainer:
     def __init__(self, model, criterion, lr=1e-3, max_norm=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 n_buckets=1, n_streams=1):
+                 n_buckets=1, n_streams=1, use_graph=False):
         self.model, self.criterion = model, criterion
         self.lr, self.max_norm, self.betas, self.eps = lr, max_norm, betas, eps
         self.group = process_group
@@ -54,6 +54,12 @@ class FlatTrainer:
         # other's MFMAs.  The result is the same sum of per-utterance gradients (order of additions aside).
         self.n_streams = max(1, n_streams)
         self.streams = None
+        # use_graph: after two eager steps the forward/backward pass (about 570 kernel launches) is captured in a
+        # HIP graph per input shape and replayed from static input buffers; the all-reduce and the optimizer
+        # (whose bias correction changes every step) stay outside the graph.
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
+        self._eager_steps = 0
         if not model._fused_ok():
             raise NotImplementedError("FlatTrainer drives the fused Conv-TasNet schedule only")
         params = model.fused_parameters()
@@ -82,6 +88,28 @@ class FlatTrainer:
     def forward_backward(self, mixture, sources):
         """Fills self.flat_g with this rank's gradient of the shard-mean loss; returns (loss, perm).
         The gradients live in flat_g only (parameters' .grad stay None)."""
+        if not self.use_graph:
+            return self._forward_backward(mixture, sources)
+        key = (tuple(mixture.shape), tuple(sources.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            if self._eager_steps < 2:              # lazy initialisation (library load, caches) happens eagerly
+                self._eager_steps += 1
+                return self._forward_backward(mixture, sources)
+            static_mix, static_src = mixture.clone(), sources.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss, perm = self._forward_backward(static_mix, static_src)
+            entry = (graph, static_mix, static_src, loss, perm)
+            self._graphs[key] = entry
+        graph, static_mix, static_src, loss, perm = entry
+        static_mix.copy_(mixture)
+        static_src.copy_(sources)
+        graph.replay()
+        return loss.clone(), perm.clone()
+
+    def _forward_backward(self, mixture, sources):
         B = mixture.shape[0]
         n = min(self.n_streams, B)
         for p in self.params:

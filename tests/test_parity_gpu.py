@@ -195,6 +195,34 @@ def test_train_two_steps_golden(golden):
             assert (diff > 1e-4).float().mean().item() <= 0.02, "param {} step {}: too many".format(k, step + 1)
 
 
+@pytest.mark.parametrize("mode", ["graph", "streams"])
+def test_trainer_execution_modes_match_eager(mode):
+    """HIP-graph replay of the forward/backward pass and sub-batches on separate streams are scheduling choices:
+    after 4 steps (2 eager warm-up steps before the capture) losses and gradients equal the eager single-stream
+    trainer's up to the order of the atomic additions."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    from speech_amd.trainer import FlatTrainer
+    cfg = O.CONFIG_SMALL
+    kw = dict(use_graph=True) if mode == "graph" else dict(n_streams=2)
+    ref = FlatTrainer(load_state(build(cfg), cases.e2e_state(cfg)), PIT1d(NegSISDR(), 2), lr=1e-3, max_norm=5.0)
+    alt = FlatTrainer(load_state(build(cfg), cases.e2e_state(cfg)), PIT1d(NegSISDR(), 2), lr=1e-3, max_norm=5.0, **kw)
+    for step in range(4):
+        mixture, sources = cases.e2e_batch(cfg, 4, 8000, step)
+        mixture, sources = mixture.to(dev()), sources.to(dev())
+        # same weights going in: gradients are compared step by step, not through Adam's sign-like first updates
+        alt.flat_p.copy_(ref.flat_p)
+        alt.m.copy_(ref.m)
+        alt.v.copy_(ref.v)
+        l0, p0 = ref.step(mixture, sources)
+        l1, p1 = alt.step(mixture, sources)
+        torch.cuda.synchronize()
+        assert torch.equal(p0, p1)
+        assert_close(l1, l0.cpu().double().numpy(), 1e-6, "loss step %d" % step)
+        scale = float(ref.flat_g.abs().max())
+        assert float((alt.flat_g - ref.flat_g).abs().max()) <= 2e-5 * scale, "gradients differ at step %d" % step
+
+
 def test_smooth_network_gradients_vs_float64():
     """With every PReLU slope at 1 (and a linear encoder) the network has no kinks, so ALL gradients are
     held to the strict max-norm bar against a float64 run of the oracle (dalpha included: its integrand

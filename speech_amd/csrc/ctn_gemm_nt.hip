@@ -260,7 +260,12 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     constexpr int PPW = TILE / 64;                        // DMA pieces per wave and operand tile
     __shared__ float red[(NTH / 64)];
 
-    int lb = blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs: renumber so that one XCD gets a contiguous range of
+    // logical blocks.  All output tiles of one (batch, chunk) slice -- which re-read the same operand rows --
+    // then share an L2 instead of fetching those rows from HBM once per XCD.
+    const int total = gridDim.x, hb = blockIdx.x;
+    const int q8 = total >> 3, rr = total & 7, xcd = hb & 7;
+    int lb = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (hb >> 3);
     const int tile_n = lb % tiles_n; lb /= tiles_n;
     const int tile_m = lb % tiles_m; lb /= tiles_m;
     const int chunk = lb % nchunks;
@@ -357,7 +362,6 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     auto compute = [&](const float* As, int t0, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const float* Bs = As + FTILE;
-        const float* A2s = As + 2 * FTILE;
 #pragma unroll
         for (int c = 0; c < FK / 8; ++c) {
             const int grp = 2 * c + half;                 // logical frame group of this half-wave
@@ -368,27 +372,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 #pragma unroll
             for (int j = 0; j < TT; ++j) bv[j] = ctn_ld4(&Bs[brow_off + j * 32 * FK + so]);
             const int tf = t0 + 4 * grp;                  // first frame of the group
-            if (BWD) {
-#pragma unroll
-                for (int i = 0; i < TT; ++i) {
-                    const f32x4 y = ctn_ld4(&A2s[arow_off + i * 32 * FK + so]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float u = ctn_prelu(y[e], a_alpha);
-                        const float du = ag[i] * av[i][e] * arstd + ac1 + (u - amean) * ac2;
-                        const bool valid = rv[i] && (!TAIL || tf + e < t_end);
-                        av[i][e] = valid ? (y[e] > 0.f ? du : a_alpha * du) : 0.f;
-                        if (do_dalpha && valid && !(y[e] > 0.f)) dalpha += du * y[e];
-                    }
-                }
-            } else if (TAIL) {
+            if (!BWD && TAIL) {          // (BWD: the in-place transform below already zeroed the tail)
 #pragma unroll
                 for (int i = 0; i < TT; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (!(tf + e < t_end)) av[i][e] = 0.f;
             }
-            if (do_rowsum) {
+            if (!BWD && do_rowsum) {
 #pragma unroll
                 for (int i = 0; i < TT; ++i) rowsum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
             }
@@ -418,6 +409,43 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     };
 
+    // NORMBWD: the A tile is transformed ONCE per block, in place, by all threads (thread -> one float4 of one
+    // row per 64 rows), before the MFMA phase: at fragment level every element would be transformed by each
+    // of the waves that read it, and the ~12 vector instructions per element then outweigh the MFMAs.
+    constexpr int XPT = TILE / 64;                      // float4 per thread
+    const int xrow = tid >> 2, xslot = tid & 3;
+    const int xgrp = xslot ^ ((xrow >> 2) & 3);         // logical frame group held by this LDS slot
+    float xg[XPT], xsum[XPT];
+    bool xv[XPT];
+#pragma unroll
+    for (int u = 0; u < XPT; ++u) {
+        const int m = m_blk + xrow + 64 * u;
+        xv[u] = m < M;
+        xg[u] = (BWD && xv[u]) ? a.a_gamma[m] : 0.f;
+        xsum[u] = 0.f;
+    }
+    const bool xreduce = BWD && tile_n == 0;
+    auto transform = [&](float* As, int t0) {
+        float* A2s = As + 2 * FTILE;
+        const int tf = t0 + 4 * xgrp;
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int o = (xrow + 64 * u) * FK + xslot * 4;
+            f32x4 v = ctn_ld4(&As[o]);
+            const f32x4 y = ctn_ld4(&A2s[o]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float uu = ctn_prelu(y[e], a_alpha);
+                const float du = xg[u] * v[e] * arstd + ac1 + (uu - amean) * ac2;
+                const bool valid = xv[u] && (tf + e < t_end);
+                v[e] = valid ? (y[e] > 0.f ? du : a_alpha * du) : 0.f;
+                if (xreduce && valid && !(y[e] > 0.f)) dalpha += du * y[e];
+            }
+            if (xreduce) xsum[u] += (v[0] + v[1]) + (v[2] + v[3]);
+            ctn_st4(&As[o], v);
+        }
+    };
+
     if (nk > 0) issue(t_begin, 0);
     for (int kt = 0; kt < nk; ++kt) {
         // every wave's pieces of tile kt must have landed before any wave reads the tile
@@ -425,6 +453,10 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         __syncthreads();
         const int t0 = t_begin + kt * FK;
         if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
+        if (BWD) {
+            transform(lds + (kt & 1) * BUF, t0);
+            __syncthreads();
+        }
         const float* As = lds + (kt & 1) * BUF;
         if (t0 + FK > t_end)
             compute(As, t0, std::true_type{});
@@ -448,7 +480,23 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             }
         }
 
-    if (do_rowsum) {   // the two half-waves hold the two halves of a row's frames
+    if (BWD && xreduce && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr)) {   // 4 neighbouring threads share a row
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            float sv = xsum[u];
+            sv += __shfl_xor(sv, 1);
+            sv += __shfl_xor(sv, 2);
+            const int m = m_blk + xrow + 64 * u;
+            if (xslot == 0 && m < M) {
+                if (m < M1) {
+                    if (a.a_rowsum) atomicAdd(a.a_rowsum + m, sv);
+                } else if (a.a_rowsum2) {
+                    atomicAdd(a.a_rowsum2 + (m - M1), sv);
+                }
+            }
+        }
+    }
+    if (!BWD && do_rowsum) {   // the two half-waves hold the two halves of a row's frames
 #pragma unroll
         for (int i = 0; i < TT; ++i) {
             float sv = rowsum[i];
@@ -464,7 +512,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     }
     if (BWD && a.a_dalpha != nullptr && tile_n == 0) {
-        float v[1] = {do_dalpha ? dalpha : 0.f};
+        float v[1] = {dalpha};
         const float tot = ctn_block_sum<1>(v, red);
         if (tid == 0) atomicAdd(a.a_dalpha + ctn_slot(), (double)tot);
     }

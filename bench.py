@@ -85,6 +85,26 @@ def instrumented_step(trainer, mixture, sources):
     return out
 
 
+def profiled_traffic(prefix, batch):
+    """Average HBM bytes per launch of the kernels whose name contains `prefix`, from the committed rocprofv3 PMC
+    summary of this benchmark at the same per-GPU batch (counters cannot be read inside the timed process);
+    None when there is no summary for this batch."""
+    path = os.path.join(ROOT, "profiles", "r1_bench_b16_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("batch_per_gpu") != batch:
+        return None
+    n = tot = 0
+    for name, k in d["kernels"].items():
+        if prefix in name:
+            n += k["launches"]
+            tot += k["launches"] * k["hbm_bytes_per_launch"]
+    return round(tot / n) if n else None
+
+
 def cpu_baseline(cfg, steps=3, batch=2):
     """The oracle's training step (same arithmetic as the reference's loop) on the host CPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -172,12 +192,13 @@ def main():
         gn = prof["gemm_nn"]
         gt = prof["gemm_nt"]
         a = gn["work"] / (gn["ms"] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="gemm_nn_kernel (f32 MFMA 32x32x2, pointwise conv fwd + dgrad)",
+        roof = dict(bound="mfma", kernel="gemm_nn_fast_kernel (f32 MFMA 32x32x2, pointwise conv fwd + dgrad)",
                     achieved=round(a, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(a / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=gn["launches"],
+                    frac=round(a / PEAK_F32_MFMA_TFLOPS, 4), traffic=profiled_traffic("gemm_nn_fast_kernel", args.batch),
+                    traffic_source="profiles/r1_bench_b16_pmc_traffic.json", launches_per_step=gn["launches"],
                     avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1))
         b = gt["work"] / (gt["ms"] * 1e-3) / 1e12
-        extra["roofline_wgrad"] = dict(bound="mfma", kernel="gemm_nt_kernel (weight gradients)", achieved=round(b, 2),
+        extra["roofline_wgrad"] = dict(bound="mfma", kernel="gemm_nt_fast_kernel (weight gradients)", achieved=round(b, 2),
                                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                                        frac=round(b / PEAK_F32_MFMA_TFLOPS, 4), launches_per_step=gt["launches"],
                                        avg_launch_us=round(gt["ms"] * 1e3 / gt["launches"], 1))
@@ -186,7 +207,8 @@ def main():
             d = prof[name]
             gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
             hb.append(dict(bound="hbm", kernel=name + "_kernel", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
-                           unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None,
+                           unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                           traffic=profiled_traffic(name, args.batch),
                            launches_per_step=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 1)))
         roof_hbm = hb
         step_ms = dt / args.steps * 1e3

@@ -237,19 +237,18 @@ void launch(const ctn_gemm_nt_args& a, hipStream_t s) {
 }
 
 // ================================================================================================
-// Fast path: TILE x TILE output tile (4 waves of TILE/2 x TILE/2), 16 frames per k-tile, operands fetched straight into LDS with
+// Fast path: TILE x TILE output tile (4 waves of TILE/2 x TILE/2), 16 or 32 frames per k-tile, operands fetched straight into LDS with
 // buffer_load_dwordx4 ... lds (scalar descriptor and k offset, loop-invariant per-lane offset: no vector
-// instructions per k-tile) into two buffers.  A DMA piece is 16 rows x 64 B written lane-linearly, so the
+// instructions per k-tile) into two buffers.  A DMA piece is 1 KiB (8 rows x 128 B) written lane-linearly, so the
 // usual row padding is impossible; instead lane (row r, slot s) of a piece FETCHES the row's 16-byte frame
-// group s ^ ((r >> 2) & 3), and the fragment reads undo that XOR: each lane then gets 4 consecutive frames
+// group s ^ f(r) (f(r) = (r >> 1) & 7 for 32-frame rows), and the fragment reads undo that XOR: each lane then gets 4 consecutive frames
 // of its row with one conflict-free ds_read_b128 and feeds them to 4 MFMAs (half-wave h owns frame groups
 // 2c + h, so every frame is summed once).  Operand transforms, the tail mask and the bias / PReLU-slope
 // reductions run on the fragments, in the shadow of the MFMAs.  Needs per-batch (not per-frame)
 // statistics, i.e. gLN; cumulative-norm launches and ragged shapes use the kernel above.
 // ================================================================================================
-constexpr int FK = 16;
 
-template <int TILE, bool BWD, int BXF>
+template <int TILE, int FK, bool BWD, int BXF>
 __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
                                                            const int tiles_n, const int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -257,7 +256,11 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     constexpr int BUF = FTILE * (BWD ? 3 : 2);           // A | B | (A2)
     constexpr int WT = TILE / 2;                          // wave tile WT x WT
     constexpr int TT = WT / 32;                           // MFMA tiles per wave and dimension
-    constexpr int PPW = TILE / 64;                        // DMA pieces per wave and operand tile
+    constexpr int SPR = FK / 4;                           // 16-byte slots (frame groups) per tile row
+    constexpr int RPP = 64 / SPR;                         // rows per 1 KiB DMA piece
+    constexpr int SH = FK == 16 ? 2 : 1;                  // slot XOR of row r: (r >> SH) & (SPR - 1)
+    constexpr int PPW = TILE / RPP / 4;                   // DMA pieces per wave and operand tile
+    static_assert(FK == 16 || FK == 32, "k-tile");
     __shared__ float red[(NTH / 64)];
 
     // Workgroups are dealt round-robin over the 8 XCDs: renumber so that one XCD gets a contiguous range of
@@ -289,26 +292,37 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
                                                        0x00020000);
     const auto rB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)b * a.bbs), 0, RS_BYTES, 0x00020000);
     const int lda = a.lda, ldab = a.ldab, lda2 = a.lda2, ldb = a.ldb;
-    // DMA lane: row lane >> 2 of the piece, LDS slot lane & 3, fetching frame group slot ^ ((row >> 2) & 3)
-    const int prow = lane >> 2, pgrp = ((lane & 3) ^ ((lane >> 4) & 3)) * 4;
-    const int voA = (prow * lda + pgrp) * 4, voAb = (prow * ldab + pgrp) * 4;
-    const int voA2 = (prow * lda2 + pgrp) * 4, voB = (prow * ldb + pgrp) * 4;
+    // DMA lane: row lane / SPR of the piece, LDS slot lane % SPR, fetching frame group slot ^ ((row >> SH) & (SPR-1))
+    // (row = row in the tile).  A lane whose frame group starts at or beyond the row pitch gets an out-of-range
+    // offset (reads zeros) on the last k-tile of a row, so no load ever leaves the buffer.
+    const int prow = lane / SPR, pslot = lane % SPR;
+    int pgrp[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp)
+        pgrp[pp] = (pslot ^ (((RPP * (wv * PPW + pp) + prow) >> SH) & (SPR - 1))) * 4;
+    const int ldlim = min(min(M1 > 0 ? lda : 0x7fffffff, M1 < M ? ldab : 0x7fffffff), min(BWD ? lda2 : 0x7fffffff, ldb));
 #define CTN_BLDS16(rs, lp, vo, so) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
     auto issue = [&](int t0, int buf) {
         float* base = lds + buf * BUF;
+        const bool edge = t0 + FK > ldlim;               // uniform; true for at most the last k-tile of a row
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) {
             const int p = wv * PPW + pp;
-            const int m = m_blk + 16 * p, n = n_blk + 16 * p;
+            const int m = m_blk + RPP * p, n = n_blk + RPP * p;
+            const int g = pgrp[pp];
+            const int oob = edge ? RS_BYTES : 0;         // added to the offsets of lanes past the row pitch
             if (m < M) {
                 if (m < M1)
-                    CTN_BLDS16(rA, base + p * 256, voA, (m * lda + t0) * 4);
+                    CTN_BLDS16(rA, base + p * 256, (prow * lda + g) * 4 + (t0 + g >= lda ? oob : 0), (m * lda + t0) * 4);
                 else
-                    CTN_BLDS16(rAb, base + p * 256, voAb, ((m - M1) * ldab + t0) * 4);
-                if (BWD) CTN_BLDS16(rA2, base + 2 * FTILE + p * 256, voA2, (m * lda2 + t0) * 4);
+                    CTN_BLDS16(rAb, base + p * 256, (prow * ldab + g) * 4 + (t0 + g >= ldab ? oob : 0),
+                               ((m - M1) * ldab + t0) * 4);
+                if (BWD)
+                    CTN_BLDS16(rA2, base + 2 * FTILE + p * 256, (prow * lda2 + g) * 4 + (t0 + g >= lda2 ? oob : 0),
+                               (m * lda2 + t0) * 4);
             }
-            if (n < N) CTN_BLDS16(rB, base + FTILE + p * 256, voB, (n * ldb + t0) * 4);
+            if (n < N) CTN_BLDS16(rB, base + FTILE + p * 256, (prow * ldb + g) * 4 + (t0 + g >= ldb ? oob : 0), (n * ldb + t0) * 4);
         }
     };
 #undef CTN_BLDS16
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     float rowsum[TT];
 #pragma unroll
     for (int i = 0; i < TT; ++i) rowsum[i] = 0.f;
-    float dalpha = 0.f;
+    double dalpha = 0.0;     // hundreds of signed terms per thread: fp32 here costs 1e-4 of the slope gradient
 
     f32x16 acc[TT][TT];
 #pragma unroll
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int fsw = (l31 >> 2) & 3;
+    const int fsw = (l31 >> SH) & (SPR - 1);
     const int arow_off = (wm0 + l31) * FK, brow_off = (wn0 + l31) * FK;
 
     auto compute = [&](const float* As, int t0, auto tail_tag) {
@@ -412,14 +426,15 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     // NORMBWD: the A tile is transformed ONCE per block, in place, by all threads (thread -> one float4 of one
     // row per 64 rows), before the MFMA phase: at fragment level every element would be transformed by each
     // of the waves that read it, and the ~12 vector instructions per element then outweigh the MFMAs.
-    constexpr int XPT = TILE / 64;                      // float4 per thread
-    const int xrow = tid >> 2, xslot = tid & 3;
-    const int xgrp = xslot ^ ((xrow >> 2) & 3);         // logical frame group held by this LDS slot
+    constexpr int XRP = NTH / SPR;                      // tile rows covered by one sweep of the block
+    constexpr int XPT = TILE / XRP;                     // float4 per thread
+    const int xrow = tid / SPR, xslot = tid % SPR;
+    const int xgrp = xslot ^ ((xrow >> SH) & (SPR - 1));   // logical frame group held by this LDS slot
     float xg[XPT], xsum[XPT];
     bool xv[XPT];
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
-        const int m = m_blk + xrow + 64 * u;
+        const int m = m_blk + xrow + XRP * u;
         xv[u] = m < M;
         xg[u] = (BWD && xv[u]) ? a.a_gamma[m] : 0.f;
         xsum[u] = 0.f;
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         const int tf = t0 + 4 * xgrp;
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
-            const int o = (xrow + 64 * u) * FK + xslot * 4;
+            const int o = (xrow + XRP * u) * FK + xslot * 4;
             f32x4 v = ctn_ld4(&As[o]);
             const f32x4 y = ctn_ld4(&A2s[o]);
 #pragma unroll
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
                 const float du = xg[u] * v[e] * arstd + ac1 + (uu - amean) * ac2;
                 const bool valid = xv[u] && (tf + e < t_end);
                 v[e] = valid ? (y[e] > 0.f ? du : a_alpha * du) : 0.f;
-                if (xreduce && valid && !(y[e] > 0.f)) dalpha += du * y[e];
+                if (xreduce && valid && !(y[e] > 0.f)) dalpha += (double)(du * y[e]);
             }
             if (xreduce) xsum[u] += (v[0] + v[1]) + (v[2] + v[3]);
             ctn_st4(&As[o], v);
@@ -480,13 +495,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             }
         }
 
-    if (BWD && xreduce && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr)) {   // 4 neighbouring threads share a row
+    if (BWD && xreduce && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr)) {   // SPR neighbouring threads share a row
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             float sv = xsum[u];
             sv += __shfl_xor(sv, 1);
             sv += __shfl_xor(sv, 2);
-            const int m = m_blk + xrow + 64 * u;
+            if (SPR == 8) sv += __shfl_xor(sv, 4);
+            const int m = m_blk + xrow + XRP * u;
             if (xslot == 0 && m < M) {
                 if (m < M1) {
                     if (a.a_rowsum) atomicAdd(a.a_rowsum + m, sv);
@@ -512,7 +528,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     }
     if (BWD && a.a_dalpha != nullptr && tile_n == 0) {
-        float v[1] = {dalpha};
+        float v[1] = {(float)dalpha};
         const float tot = ctn_block_sum<1>(v, red);
         if (tid == 0) atomicAdd(a.a_dalpha + ctn_slot(), (double)tot);
     }
@@ -520,27 +536,26 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 
 bool fast_ok(const ctn_gemm_nt_args& a) {
     if (a.M < 16 || a.N < 16) return false;
-    if (a.M % 16 != 0 || a.N % 16 != 0 || a.M1 % 16 != 0) return false;
-    // k-tiles are fetched whole: rows must end on a 16-frame boundary so that the last tile stays inside the buffer
-    if (a.M1 > 0 && a.lda % 16 != 0) return false;
-    if (a.M1 < a.M && a.ldab % 16 != 0) return false;
-    if (a.ldb % 16 != 0) return false;
+    if (a.M % 16 != 0 || a.N % 16 != 0 || a.M1 % 16 != 0) return false;    // DMA pieces are 8 or 16 whole rows
     const int64_t lim = 0x40000000 / 4 - 4096;
     if ((int64_t)a.M * a.lda >= lim || (int64_t)a.M * a.ldab >= lim || (int64_t)a.N * a.ldb >= lim) return false;
     if (a.aflags & CTN_XF_NORMBWD) {
-        if (a.a_sst != 0 || a.lda2 % 16 != 0 || (int64_t)a.M * a.lda2 >= lim) return false;
+        if (a.a_sst != 0 || (int64_t)a.M * a.lda2 >= lim) return false;
     }
     if ((a.bflags & CTN_XF_NORM) && a.b_sst != 0) return false;
     return true;
 }
 
+// k-tile: 32 frames (half the barriers per MFMA) unless the NORMBWD variant's third operand tile would then cost
+// a resident block per CU.
 template <int TILE, bool BWD, int BXF>
 void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
+    constexpr int FK = BWD ? 16 : 32;
     const int tiles_m = ctn_cdiv(a.M, TILE), tiles_n = ctn_cdiv(a.N, TILE);
     const int nchunks = ctn_cdiv(a.T, a.kchunk);
     const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
     const size_t shmem = (size_t)2 * TILE * FK * (BWD ? 3 : 2) * sizeof(float);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<TILE, BWD, BXF>), dim3(total), dim3(NTH), shmem, s, a, tiles_m, tiles_n,
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<TILE, FK, BWD, BXF>), dim3(total), dim3(NTH), shmem, s, a, tiles_m, tiles_n,
                        nchunks);
 }
 

@@ -70,12 +70,15 @@ def instrumented_step(trainer, mixture, sources):
     ops.gemm_nt = wrap("gemm_nt", lambda M, N, T, batch, *a, **k: 2.0 * M * N * T * batch)
     ops.dw_fwd = wrap("dw_fwd", lambda x, w, bias, y, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
     ops.dw_bwd = wrap("dw_bwd", lambda dn2, x, *a, **k: 4.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
-    graph_mode, trainer.use_graph = trainer.use_graph, False     # the timed launches must run eagerly
+    # per-kernel timing needs eager launches on ONE stream (two sub-batch streams overlap kernels, which makes a
+    # kernel's own duration meaningless); the work is the same full per-GPU batch
+    graph_mode, trainer.use_graph = trainer.use_graph, False
+    n_streams, trainer.n_streams = trainer.n_streams, 1
     try:
         trainer.step(mixture, sources)
         torch.cuda.synchronize()
     finally:
-        trainer.use_graph = graph_mode
+        trainer.use_graph, trainer.n_streams = graph_mode, n_streams
         for k, f in orig.items():
             setattr(ops, k, f)
     out = {}
@@ -132,8 +135,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
-    ap.add_argument("--graph", action="store_true", help="replay the forward/backward pass from a HIP graph")
-    ap.add_argument("--streams", type=int, default=1, help="sub-batches of a rank's shard run on separate HIP streams")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="launch every kernel eagerly instead of replaying the forward/backward pass from a HIP graph")
+    ap.add_argument("--streams", type=int, default=2, help="sub-batches of a rank's shard run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -195,7 +199,9 @@ def main():
         roof = dict(bound="mfma", kernel="gemm_nn_fast_kernel (f32 MFMA 32x32x2, pointwise conv fwd + dgrad)",
                     achieved=round(a, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(a / PEAK_F32_MFMA_TFLOPS, 4), traffic=profiled_traffic("gemm_nn_fast_kernel", args.batch),
-                    traffic_source="profiles/r1_bench_b16_pmc_traffic.json", launches_per_step=gn["launches"],
+                    traffic_source="profiles/r1_bench_b16_pmc_traffic.json",
+                    mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph is the profiled command)",
+                    launches_per_step=gn["launches"],
                     avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1))
         b = gt["work"] / (gt["ms"] * 1e-3) / 1e12
         extra["roofline_wgrad"] = dict(bound="mfma", kernel="gemm_nt_fast_kernel (weight gradients)", achieved=round(b, 2),
@@ -239,7 +245,8 @@ def main():
                                    "32000-sample (4 s @ 8 kHz) mixtures, full training step "
                                    "(fwd + PIT SI-SDR + bwd + all-reduce + clip 5 + Adam 1e-3)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": "dp{}".format(world), "final_loss": round(final_loss, 4)},
+                       "parallelism": "dp{}".format(world), "sub_batch_streams": args.streams,
+                       "hip_graph": bool(args.graph), "final_loss": round(final_loss, 4)},
             "roofline": roof,
             "roofline_hbm": roof_hbm,
             "cpu_baseline": cpu,

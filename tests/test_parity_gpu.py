@@ -195,7 +195,7 @@ def test_train_two_steps_golden(golden):
             assert (diff > 1e-4).float().mean().item() <= 0.02, "param {} step {}: too many".format(k, step + 1)
 
 
-@pytest.mark.parametrize("mode", ["graph", "streams"])
+@pytest.mark.parametrize("mode", ["graph", "streams", "graph+streams"])
 def test_trainer_execution_modes_match_eager(mode):
     """HIP-graph replay of the forward/backward pass and sub-batches on separate streams are scheduling choices:
     after 4 steps (2 eager warm-up steps before the capture) losses and gradients equal the eager single-stream
@@ -204,7 +204,7 @@ def test_trainer_execution_modes_match_eager(mode):
     from speech_amd.criterion.sdr import NegSISDR
     from speech_amd.trainer import FlatTrainer
     cfg = O.CONFIG_SMALL
-    kw = dict(use_graph=True) if mode == "graph" else dict(n_streams=2)
+    kw = dict(use_graph="graph" in mode, n_streams=2 if "streams" in mode else 1)
     ref = FlatTrainer(load_state(build(cfg), cases.e2e_state(cfg)), PIT1d(NegSISDR(), 2), lr=1e-3, max_norm=5.0)
     alt = FlatTrainer(load_state(build(cfg), cases.e2e_state(cfg)), PIT1d(NegSISDR(), 2), lr=1e-3, max_norm=5.0, **kw)
     for step in range(4):

@@ -142,17 +142,28 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("CTN_BENCH_TRACE_AFTER"):      # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CTN_BENCH_TRACE_AFTER"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # CTN_BENCH_REHEARSAL=gloo: every rank on cuda:0 with the gloo backend -- a rehearsal of the multi-rank control
+    # flow (graph capture beside a process group, all-reduce, max-over-ranks timing) on a one-GPU box, not a result
+    rehearsal = os.environ.get("CTN_BENCH_REHEARSAL") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from speech_amd.criterion.pit import PIT1d
     from speech_amd.criterion.sdr import NegSISDR
@@ -183,7 +194,7 @@ def main():
         losses.append(loss)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    t = torch.tensor([dt], device="cpu" if rehearsal else device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
@@ -191,8 +202,11 @@ def main():
 
     roof = roof_hbm = None
     extra = {}
-    if rank == 0 and not args.no_roofline:
+    prof = None
+    if not args.no_roofline:
+        # every rank runs the instrumented step: it contains the gradient all-reduce, a collective
         prof = instrumented_step(trainer, *batches[0])
+    if rank == 0 and prof is not None:
         gn = prof["gemm_nn"]
         gt = prof["gemm_nt"]
         a = gn["work"] / (gn["ms"] * 1e-3) / 1e12

@@ -18,6 +18,12 @@ from .functional import ConvTasNetFn, flat_layout
 def allreduce_flat(flat, n_buckets=1, group=None):
     """Sum-all-reduce a flat gradient buffer in `n_buckets` contiguous chunks (asynchronously, then wait).
     The result is independent of n_buckets; with the NCCL backend this is RCCL over xGMI."""
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal / debugging without RCCL (e.g. several ranks on one GPU): reduce a host copy
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return flat
     n = flat.numel()
     n_buckets = max(1, min(n_buckets, n))
     per = (n + n_buckets - 1) // n_buckets
@@ -99,7 +105,8 @@ class FlatTrainer:
             static_mix, static_src = mixture.clone(), sources.clone()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: a process group's watchdog thread may touch the device while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 loss, perm = self._forward_backward(static_mix, static_src)
             entry = (graph, static_mix, static_src, loss, perm)
             self._graphs[key] = entry

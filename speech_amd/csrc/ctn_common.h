@@ -72,6 +72,20 @@ __device__ __forceinline__ float ctn_block_sum(float (&v)[NV], float* smem) {
     return tot;
 }
 
+// fp64 block sum of one value per thread (slope gradients: signed terms that cancel, so fp32 partial sums cost
+// 1e-4 of the result).  Thread 0 holds the total; smem needs blockDim.x / 64 doubles.
+__device__ __forceinline__ double ctn_block_sum_f64(double v, double* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const double s = ctn_wave_sum(v);
+    if (lane == 0) smem[wave] = s;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < nw; ++w) tot += smem[w];
+    __syncthreads();
+    return tot;
+}
+
 __device__ __forceinline__ f32x4 ctn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void ctn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 

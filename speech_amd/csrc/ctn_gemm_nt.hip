@@ -528,9 +528,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     }
     if (BWD && a.a_dalpha != nullptr && tile_n == 0) {
-        float v[1] = {(float)dalpha};
-        const float tot = ctn_block_sum<1>(v, red);
-        if (tid == 0) atomicAdd(a.a_dalpha + ctn_slot(), (double)tot);
+        __shared__ double dred[NTH / 64];
+        const double tot = ctn_block_sum_f64(dalpha, dred);
+        if (tid == 0) atomicAdd(a.a_dalpha + ctn_slot(), tot);
     }
 }
 

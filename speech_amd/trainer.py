@@ -105,9 +105,17 @@ class FlatTrainer:
             static_mix, static_src = mixture.clone(), sources.clone()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            # thread_local: a process group's watchdog thread may touch the device while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                loss, perm = self._forward_backward(static_mix, static_src)
+            try:
+                # thread_local: a process group's watchdog thread may touch the device while this thread captures
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    loss, perm = self._forward_backward(static_mix, static_src)
+            except RuntimeError as exc:            # capture refused: keep training with eager launches
+                import sys
+                print("FlatTrainer: HIP graph capture failed ({}); continuing with eager launches".format(exc),
+                      file=sys.stderr)
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return self._forward_backward(mixture, sources)
             entry = (graph, static_mix, static_src, loss, perm)
             self._graphs[key] = entry
         graph, static_mix, static_src, loss, perm = entry

@@ -110,7 +110,7 @@ typedef struct {
     const float* R; int64_t ldr, rbs; /* residual (HEADS rows < Mo, ADD) */
     float* Y2; int64_t ldy2, y2bs;    /* HEADS rows >= Mo */
     int32_t accumulate;               /* HEADS: Y2 += instead of = */
-    int32_t pad0;
+    int32_t tile_width;               /* output-tile columns of the LDS-DMA kernel: 0 = choose, 64 or 128 */
     const float* ealpha;              /* STATS / PRELUBWD / NORMBWD slope (NULL = 1, i.e. no PReLU) */
     double* esums;                    /* [batch][CTN_STAT_SLOTS][2] (+=), PRELUBWD: [CTN_STAT_SLOTS] */
     float* ecol; int64_t ecol_bs, ecol_ld;   /* cLN: [batch][2][ecol_ld] column sums (+=) */

@@ -820,6 +820,7 @@ int pick_fbn(const ctn_gemm_nn_args& a) {
         g_forced_fbn = (v == 64 || v == 128) ? v : 0;
     }
     if (g_forced_fbn) return g_forced_fbn;
+    if (a.tile_width == 64 || a.tile_width == 128) return a.tile_width;
     static const int slots = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||

@@ -468,10 +468,12 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         __syncthreads();
         const int t0 = t_begin + kt * FK;
         if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
+#ifndef CTN_DBG_NT_NO_TRANSFORM
         if (BWD) {
             transform(lds + (kt & 1) * BUF, t0);
             __syncthreads();
         }
+#endif
         const float* As = lds + (kt & 1) * BUF;
         if (t0 + FK > t_end)
             compute(As, t0, std::true_type{});
@@ -480,6 +482,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     }
 
     // partial tile -> C
+#ifdef CTN_DBG_NT_NO_ATOMICS
+    if (acc[0][0][0] == 123.456f)
+#endif
 #pragma unroll
     for (int i = 0; i < TT; ++i)
 #pragma unroll

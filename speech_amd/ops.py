@@ -220,10 +220,11 @@ def norm_bwd_apply(dn, x, alpha, stat, gamma, dx, dalpha):
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, xflags=0, X2=None, alpha=None,
             stat=None, gamma=None, beta=None, bias=None, bias2=None, emode=EPI_STORE, Mo=0, R=None, Y2=None,
-            accumulate=False, ealpha=None, eacc=None, E=None, estat=None, egamma=None, esums=None):
+            accumulate=False, ealpha=None, eacc=None, E=None, estat=None, egamma=None, esums=None, tile_width=0):
     """Y[b] = A(k-major) . xform(X[b]); see ctn_gemm_nn in include/ctn.h.  X/Xb/X2/Y/Y2/R/E are act views."""
     lib = _lib.load()
     a = _lib.GemmNNArgs()
+    a.tile_width = tile_width
     a.M, a.T, a.K, a.batch = M, T, K, batch
     a.A, a.lda = _ptr(A), lda
     a.A2, a.lda2 = _ptr(A2), lda2

@@ -237,7 +237,7 @@ void launch(const ctn_gemm_nt_args& a, hipStream_t s) {
 }
 
 // ================================================================================================
-// Fast path: TILE x TILE output tile (4 waves of TILE/2 x TILE/2), 16 or 32 frames per k-tile, operands fetched straight into LDS with
+// Fast path: TM x TN output tile (4 waves of TM/2 x TN/2), 16 or 32 frames per k-tile, operands fetched straight into LDS with
 // buffer_load_dwordx4 ... lds (scalar descriptor and k offset, loop-invariant per-lane offset: no vector
 // instructions per k-tile) into two buffers.  A DMA piece is 1 KiB (8 rows x 128 B) written lane-linearly, so the
 // usual row padding is impossible; instead lane (row r, slot s) of a piece FETCHES the row's 16-byte frame
@@ -248,18 +248,18 @@ void launch(const ctn_gemm_nt_args& a, hipStream_t s) {
 // statistics, i.e. gLN; cumulative-norm launches and ragged shapes use the kernel above.
 // ================================================================================================
 
-template <int TILE, int FK, bool BWD, int BXF>
+template <int TM, int TN, int FK, bool BWD, int BXF>
 __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
                                                            const int tiles_n, const int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int FTILE = TILE * FK;                      // floats per operand tile
-    constexpr int BUF = FTILE * (BWD ? 3 : 2);           // A | B | (A2)
-    constexpr int WT = TILE / 2;                          // wave tile WT x WT
-    constexpr int TT = WT / 32;                           // MFMA tiles per wave and dimension
+    constexpr int FTA = TM * FK, FTB = TN * FK;           // floats per operand tile
+    constexpr int BUF = FTA + FTB + (BWD ? FTA : 0);     // A | B | (A2)
+    constexpr int WTM = TM / 2, WTN = TN / 2;             // wave tile WTM x WTN
+    constexpr int TTM = WTM / 32, TTN = WTN / 32;         // MFMA tiles per wave
     constexpr int SPR = FK / 4;                           // 16-byte slots (frame groups) per tile row
     constexpr int RPP = 64 / SPR;                         // rows per 1 KiB DMA piece
     constexpr int SH = FK == 16 ? 2 : 1;                  // slot XOR of row r: (r >> SH) & (SPR - 1)
-    constexpr int PPW = TILE / RPP / 4;                   // DMA pieces per wave and operand tile
+    constexpr int PPA = TM / RPP / 4, PPB = TN / RPP / 4; // DMA pieces per wave and operand tile
     static_assert(FK == 16 || FK == 32, "k-tile");
     __shared__ float red[(NTH / 64)];
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     const int tile_m = lb % tiles_m; lb /= tiles_m;
     const int chunk = lb % nchunks;
     const int b = lb / nchunks;
-    const int m_blk = tile_m * TILE, n_blk = tile_n * TILE;
+    const int m_blk = tile_m * TM, n_blk = tile_n * TN;
     const int M = a.M, N = a.N, M1 = a.M1;
     const int t_begin = chunk * a.kchunk, t_end = min(t_begin + a.kchunk, a.T);
     const int nk = (t_end - t_begin + FK - 1) / FK;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
+    const int wm0 = (wave >> 1) * WTM, wn0 = (wave & 1) * WTN;
 
     constexpr int RS_BYTES = 0x40000000;
     const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A ? a.A + (int64_t)b * a.abs_ : a.Ab), 0, RS_BYTES,
@@ -296,22 +296,23 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     // (row = row in the tile).  A lane whose frame group starts at or beyond the row pitch gets an out-of-range
     // offset (reads zeros) on the last k-tile of a row, so no load ever leaves the buffer.
     const int prow = lane / SPR, pslot = lane % SPR;
-    int pgrp[PPW];
+    int pgA[PPA], pgB[PPB];
 #pragma unroll
-    for (int pp = 0; pp < PPW; ++pp)
-        pgrp[pp] = (pslot ^ (((RPP * (wv * PPW + pp) + prow) >> SH) & (SPR - 1))) * 4;
+    for (int pp = 0; pp < PPA; ++pp) pgA[pp] = (pslot ^ (((RPP * (wv * PPA + pp) + prow) >> SH) & (SPR - 1))) * 4;
+#pragma unroll
+    for (int pp = 0; pp < PPB; ++pp) pgB[pp] = (pslot ^ (((RPP * (wv * PPB + pp) + prow) >> SH) & (SPR - 1))) * 4;
     const int ldlim = min(min(M1 > 0 ? lda : 0x7fffffff, M1 < M ? ldab : 0x7fffffff), min(BWD ? lda2 : 0x7fffffff, ldb));
 #define CTN_BLDS16(rs, lp, vo, so) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
     auto issue = [&](int t0, int buf) {
         float* base = lds + buf * BUF;
         const bool edge = t0 + FK > ldlim;               // uniform; true for at most the last k-tile of a row
+        const int oob = edge ? RS_BYTES : 0;             // added to the offsets of lanes past the row pitch
 #pragma unroll
-        for (int pp = 0; pp < PPW; ++pp) {
-            const int p = wv * PPW + pp;
-            const int m = m_blk + RPP * p, n = n_blk + RPP * p;
-            const int g = pgrp[pp];
-            const int oob = edge ? RS_BYTES : 0;         // added to the offsets of lanes past the row pitch
+        for (int pp = 0; pp < PPA; ++pp) {
+            const int p = wv * PPA + pp;
+            const int m = m_blk + RPP * p;
+            const int g = pgA[pp];
             if (m < M) {
                 if (m < M1)
                     CTN_BLDS16(rA, base + p * 256, (prow * lda + g) * 4 + (t0 + g >= lda ? oob : 0), (m * lda + t0) * 4);
@@ -319,10 +320,16 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
                     CTN_BLDS16(rAb, base + p * 256, (prow * ldab + g) * 4 + (t0 + g >= ldab ? oob : 0),
                                ((m - M1) * ldab + t0) * 4);
                 if (BWD)
-                    CTN_BLDS16(rA2, base + 2 * FTILE + p * 256, (prow * lda2 + g) * 4 + (t0 + g >= lda2 ? oob : 0),
+                    CTN_BLDS16(rA2, base + FTA + FTB + p * 256, (prow * lda2 + g) * 4 + (t0 + g >= lda2 ? oob : 0),
                                (m * lda2 + t0) * 4);
             }
-            if (n < N) CTN_BLDS16(rB, base + FTILE + p * 256, (prow * ldb + g) * 4 + (t0 + g >= ldb ? oob : 0), (n * ldb + t0) * 4);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPB; ++pp) {
+            const int p = wv * PPB + pp;
+            const int n = n_blk + RPP * p;
+            const int g = pgB[pp];
+            if (n < N) CTN_BLDS16(rB, base + FTA + p * 256, (prow * ldb + g) * 4 + (t0 + g >= ldb ? oob : 0), (n * ldb + t0) * 4);
         }
     };
 #undef CTN_BLDS16
@@ -330,18 +337,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     // per-lane row constants
     const float a_alpha = a.a_alpha ? a.a_alpha[0] : 1.f;
     const float b_alpha = a.b_alpha ? a.b_alpha[0] : 1.f;
-    float ag[TT], bg[TT], bb[TT];
-    bool rv[TT];
+    float bg[TTN], bb[TTN];
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-        ag[i] = 0.f, bg[i] = 1.f, bb[i] = 0.f;
-        const int m = m_blk + wm0 + i * 32 + l31;
-        rv[i] = m < M;
-        if (BWD && rv[i]) ag[i] = a.a_gamma[m];
-        const int n = n_blk + wn0 + i * 32 + l31;
+    for (int j = 0; j < TTN; ++j) {
+        bg[j] = 1.f, bb[j] = 0.f;
+        const int n = n_blk + wn0 + j * 32 + l31;
         if ((BXF & CTN_XF_NORM) && n < N) {
-            bg[i] = a.b_gamma[n];
-            bb[i] = a.b_beta[n];
+            bg[j] = a.b_gamma[n];
+            bb[j] = a.b_beta[n];
         }
     }
     float amean = 0.f, arstd = 1.f, ac1 = 0.f, ac2 = 0.f, bmean = 0.f, brstd = 1.f;
@@ -356,17 +359,16 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     // the two waves of a tile row read the same A rows: one of them reduces, and only in the first tile column
     const bool reducer = (tile_n == 0) && ((wave & 1) == 0);
     const bool do_rowsum = reducer && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr);
-    const bool do_dalpha = BWD && reducer && (a.a_dalpha != nullptr);
-    float rowsum[TT];
+    float rowsum[TTM];
 #pragma unroll
-    for (int i = 0; i < TT; ++i) rowsum[i] = 0.f;
+    for (int i = 0; i < TTM; ++i) rowsum[i] = 0.f;
     double dalpha = 0.0;     // hundreds of signed terms per thread: fp32 here costs 1e-4 of the slope gradient
 
-    f32x16 acc[TT][TT];
+    f32x16 acc[TTM][TTN];
 #pragma unroll
-    for (int i = 0; i < TT; ++i)
+    for (int i = 0; i < TTM; ++i)
 #pragma unroll
-        for (int j = 0; j < TT; ++j)
+        for (int j = 0; j < TTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -375,30 +377,30 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 
     auto compute = [&](const float* As, int t0, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        const float* Bs = As + FTILE;
+        const float* Bs = As + FTA;
 #pragma unroll
         for (int c = 0; c < FK / 8; ++c) {
             const int grp = 2 * c + half;                 // logical frame group of this half-wave
             const int so = ((grp ^ fsw) * 4);             // its LDS slot in this lane's rows
-            f32x4 av[TT], bv[TT];
+            f32x4 av[TTM], bv[TTN];
 #pragma unroll
-            for (int i = 0; i < TT; ++i) av[i] = ctn_ld4(&As[arow_off + i * 32 * FK + so]);
+            for (int i = 0; i < TTM; ++i) av[i] = ctn_ld4(&As[arow_off + i * 32 * FK + so]);
 #pragma unroll
-            for (int j = 0; j < TT; ++j) bv[j] = ctn_ld4(&Bs[brow_off + j * 32 * FK + so]);
+            for (int j = 0; j < TTN; ++j) bv[j] = ctn_ld4(&Bs[brow_off + j * 32 * FK + so]);
             const int tf = t0 + 4 * grp;                  // first frame of the group
             if (!BWD && TAIL) {          // (BWD: the in-place transform below already zeroed the tail)
 #pragma unroll
-                for (int i = 0; i < TT; ++i)
+                for (int i = 0; i < TTM; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (!(tf + e < t_end)) av[i][e] = 0.f;
             }
             if (!BWD && do_rowsum) {
 #pragma unroll
-                for (int i = 0; i < TT; ++i) rowsum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
+                for (int i = 0; i < TTM; ++i) rowsum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
             }
 #pragma unroll
-            for (int j = 0; j < TT; ++j) {
+            for (int j = 0; j < TTN; ++j) {
                 if (BXF & CTN_XF_PRELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bv[j][e] = ctn_prelu(bv[j][e], b_alpha);
@@ -416,9 +418,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < TT; ++i)
+                for (int i = 0; i < TTM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TT; ++j)
+                    for (int j = 0; j < TTN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
         }
     };
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     // row per 64 rows), before the MFMA phase: at fragment level every element would be transformed by each
     // of the waves that read it, and the ~12 vector instructions per element then outweigh the MFMAs.
     constexpr int XRP = NTH / SPR;                      // tile rows covered by one sweep of the block
-    constexpr int XPT = TILE / XRP;                     // float4 per thread
+    constexpr int XPT = TM / XRP;                       // float4 per thread
     const int xrow = tid / SPR, xslot = tid % SPR;
     const int xgrp = xslot ^ ((xrow >> SH) & (SPR - 1));   // logical frame group held by this LDS slot
     float xg[XPT], xsum[XPT];
@@ -436,12 +438,12 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     for (int u = 0; u < XPT; ++u) {
         const int m = m_blk + xrow + XRP * u;
         xv[u] = m < M;
-        xg[u] = (BWD && xv[u]) ? a.a_gamma[m] : 0.f;
+        xg[u] = (BWD && xv[u]) ? a.a_gamma[m] * arstd : 0.f;
         xsum[u] = 0.f;
     }
     const bool xreduce = BWD && tile_n == 0;
     auto transform = [&](float* As, int t0) {
-        float* A2s = As + 2 * FTILE;
+        float* A2s = As + FTA + FTB;
         const int tf = t0 + 4 * xgrp;
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
@@ -449,11 +451,11 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             f32x4 v = ctn_ld4(&As[o]);
             const f32x4 y = ctn_ld4(&A2s[o]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float uu = ctn_prelu(y[e], a_alpha);
-                const float du = xg[u] * v[e] * arstd + ac1 + (uu - amean) * ac2;
+            for (int e = 0; e < 4; ++e) {      // 8 vector ops per element: this loop is 20 % of the launch
+                const float sl = y[e] > 0.f ? 1.f : a_alpha;          // PReLU slope at y
+                const float du = xg[u] * v[e] + ac1 + (sl * y[e] - amean) * ac2;   // xg = gamma * rstd
                 const bool valid = xv[u] && (tf + e < t_end);
-                v[e] = valid ? (y[e] > 0.f ? du : a_alpha * du) : 0.f;
+                v[e] = valid ? sl * du : 0.f;
                 if (xreduce && valid && !(y[e] > 0.f)) dalpha += (double)(du * y[e]);
             }
             if (xreduce) xsum[u] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -461,24 +463,44 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     };
 
-    if (nk > 0) issue(t_begin, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // every wave's pieces of tile kt must have landed before any wave reads the tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int t0 = t_begin + kt * FK;
-        if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
-#ifndef CTN_DBG_NT_NO_TRANSFORM
-        if (BWD) {
-            transform(lds + (kt & 1) * BUF, t0);
+    if (!BWD) {
+        if (nk > 0) issue(t_begin, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            // every wave's pieces of tile kt must have landed before any wave reads the tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            const int t0 = t_begin + kt * FK;
+            if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
+            const float* As = lds + (kt & 1) * BUF;
+            if (t0 + FK > t_end)
+                compute(As, t0, std::true_type{});
+            else
+                compute(As, t0, std::false_type{});
         }
-#endif
-        const float* As = lds + (kt & 1) * BUF;
-        if (t0 + FK > t_end)
-            compute(As, t0, std::true_type{});
-        else
-            compute(As, t0, std::false_type{});
+    } else {
+        // NORMBWD: ring of three buffers.  In iteration kt the waves run the MFMAs of tile kt (transformed in the
+        // previous iteration) and, in the same instruction stream, transform tile kt+1 (landed one iteration
+        // ago), while the DMA of tile kt+2 is in flight: one barrier per k-tile and the transform's vector work
+        // sits in the MFMAs' shadow instead of in a phase of its own.
+        if (nk > 0) {
+            issue(t_begin, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (nk > 1) issue(t_begin + FK, 1);
+            transform(lds, t_begin);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 have landed
+            __syncthreads();                                     // tile kt transformed, tile kt+1 complete, tile kt-1 free
+            const int t0 = t_begin + kt * FK;
+            if (kt + 2 < nk) issue(t0 + 2 * FK, (kt + 2) % 3);
+            if (kt + 1 < nk) transform(lds + ((kt + 1) % 3) * BUF, t0 + FK);
+            const float* As = lds + (kt % 3) * BUF;
+            if (t0 + FK > t_end)
+                compute(As, t0, std::true_type{});
+            else
+                compute(As, t0, std::false_type{});
+        }
     }
 
     // partial tile -> C
@@ -486,9 +508,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     if (acc[0][0][0] == 123.456f)
 #endif
 #pragma unroll
-    for (int i = 0; i < TT; ++i)
+    for (int i = 0; i < TTM; ++i)
 #pragma unroll
-        for (int j = 0; j < TT; ++j) {
+        for (int j = 0; j < TTN; ++j) {
             const int n = n_blk + wn0 + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     }
     if (!BWD && do_rowsum) {   // the two half-waves hold the two halves of a row's frames
 #pragma unroll
-        for (int i = 0; i < TT; ++i) {
+        for (int i = 0; i < TTM; ++i) {
             float sv = rowsum[i];
             sv += __shfl_xor(sv, 32);
             const int m = m_blk + wm0 + i * 32 + l31;
@@ -553,36 +575,44 @@ bool fast_ok(const ctn_gemm_nt_args& a) {
 
 // k-tile: 32 frames (half the barriers per MFMA) unless the NORMBWD variant's third operand tile would then cost
 // a resident block per CU.
-template <int TILE, bool BWD, int BXF>
+// k-tile: 32 frames (half the barriers per MFMA) for the plain variants, 16 with the NORMBWD variant's ring of
+// three buffers.  Tile: 64 x 64, or 64 x 128 for NORMBWD when N allows: the transformed operand is then
+// transformed once, not once per tile column, and each barrier covers twice the MFMAs.
+bool wide_n(const ctn_gemm_nt_args& a) { return (a.aflags & CTN_XF_NORMBWD) && a.N % 128 == 0; }
+
+template <int TM, int TN, bool BWD, int BXF>
 void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     constexpr int FK = BWD ? 16 : 32;
-    const int tiles_m = ctn_cdiv(a.M, TILE), tiles_n = ctn_cdiv(a.N, TILE);
+    const int tiles_m = ctn_cdiv(a.M, TM), tiles_n = ctn_cdiv(a.N, TN);
     const int nchunks = ctn_cdiv(a.T, a.kchunk);
     const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
-    const size_t shmem = (size_t)2 * TILE * FK * (BWD ? 3 : 2) * sizeof(float);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<TILE, FK, BWD, BXF>), dim3(total), dim3(NTH), shmem, s, a, tiles_m, tiles_n,
+    const size_t tile_floats = (size_t)(TM + TN + (BWD ? TM : 0)) * FK;
+    const size_t shmem = (BWD ? 3 : 2) * tile_floats * sizeof(float);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF>), dim3(total), dim3(NTH), shmem, s, a, tiles_m, tiles_n,
                        nchunks);
 }
 
-template <int TILE>
-void launch_fast_t(const ctn_gemm_nt_args& a, hipStream_t s) {
+void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) {
     const int bxf = a.bflags & (CTN_XF_PRELU | CTN_XF_NORM);
     if (a.aflags & CTN_XF_NORMBWD) {
-        if (bxf == 0) launch_fast_x<TILE, true, 0>(a, s);
-        else if (bxf == CTN_XF_PRELU) launch_fast_x<TILE, true, CTN_XF_PRELU>(a, s);
-        else if (bxf == CTN_XF_NORM) launch_fast_x<TILE, true, CTN_XF_NORM>(a, s);
-        else launch_fast_x<TILE, true, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
+        if (wide_n(a)) {
+            if (bxf == 0) launch_fast_x<64, 128, true, 0>(a, s);
+            else if (bxf == CTN_XF_PRELU) launch_fast_x<64, 128, true, CTN_XF_PRELU>(a, s);
+            else if (bxf == CTN_XF_NORM) launch_fast_x<64, 128, true, CTN_XF_NORM>(a, s);
+            else launch_fast_x<64, 128, true, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
+        } else {
+            if (bxf == 0) launch_fast_x<64, 64, true, 0>(a, s);
+            else if (bxf == CTN_XF_PRELU) launch_fast_x<64, 64, true, CTN_XF_PRELU>(a, s);
+            else if (bxf == CTN_XF_NORM) launch_fast_x<64, 64, true, CTN_XF_NORM>(a, s);
+            else launch_fast_x<64, 64, true, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
+        }
     } else {
-        if (bxf == 0) launch_fast_x<TILE, false, 0>(a, s);
-        else if (bxf == CTN_XF_PRELU) launch_fast_x<TILE, false, CTN_XF_PRELU>(a, s);
-        else if (bxf == CTN_XF_NORM) launch_fast_x<TILE, false, CTN_XF_NORM>(a, s);
-        else launch_fast_x<TILE, false, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
+        if (bxf == 0) launch_fast_x<64, 64, false, 0>(a, s);
+        else if (bxf == CTN_XF_PRELU) launch_fast_x<64, 64, false, CTN_XF_PRELU>(a, s);
+        else if (bxf == CTN_XF_NORM) launch_fast_x<64, 64, false, CTN_XF_NORM>(a, s);
+        else launch_fast_x<64, 64, false, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
     }
 }
-
-// 64 x 64 tiles: every block adds its whole tile to C with atomics, whose volume (blocks x tile bytes) is what
-// limits this kernel -- 1024 blocks of 64 x 64 fill the chip with a quarter of the atomic traffic of 128 x 128.
-void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) { launch_fast_t<64>(a, s); }
 
 bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
     return p && ctn_aligned16(p) && ld % 4 == 0 && bs % 4 == 0 && ld >= T;

@@ -262,10 +262,9 @@ def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, 
     _lib.check(lib.ctn_gemm_nn(C.byref(a), _stream()), "ctn_gemm_nn")
 
 
-def pick_kchunk(T, batch, tiles):
+def pick_kchunk(T, batch, tiles, target_blocks=1024):
     """Time steps per wgrad block: one generation of 4 blocks on each of the 256 CUs (every block ends with
     atomic adds of its whole output tile, the cost that grows with the number of chunks), chunks >= 256 frames."""
-    target_blocks = 1024
     chunks = max(1, target_blocks // max(1, batch * tiles))
     k = (T + chunks - 1) // chunks
     k = max(256, (k + 31) // 32 * 32)
@@ -295,8 +294,11 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
     a.a_rowsum, a.a_rowsum2, a.a_dalpha = _ptr(a_rowsum), _ptr(a_rowsum2), _ptr(a_dalpha)
     a.B, a.ldb, a.bbs = _ptr(B), B.stride(1), B.stride(0)
     a.bflags = bflags
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)      # the library's wgrad kernel works on 64 x 64 output tiles
-    a.kchunk = kchunk or pick_kchunk(T, batch, tiles)
+    # the library's wgrad kernel works on 64 x 64 output tiles, 64 x 128 for the NORMBWD variant when N allows
+    tn = 128 if (aflags & XF_NORMBWD) and N % 128 == 0 else 64
+    tiles = ((M + 63) // 64) * ((N + tn - 1) // tn)
+    # one generation of resident blocks: 4 per CU (3 for the wide NORMBWD tile, whose ring of LDS buffers is larger)
+    a.kchunk = kchunk or pick_kchunk(T, batch, tiles, 768 if tn == 128 else 1024)
     a.b_alpha = _ptr(b_alpha)
     if b_stat is not None:
         a.b_mean, a.b_rstd, a.b_ssb, a.b_sst = _ptr(b_stat.mean), _ptr(b_stat.rstd), b_stat.sb, b_stat.st

@@ -246,7 +246,7 @@ def test_gemm_nn_normbwd_epilogue_and_load(cln, gemm_path):
     torch.cuda.synchronize()
     assert_close(Y2, ref2, 1e-4, "normbwd on load")
     # the same transform inside the weight-gradient GEMM, with bias / slope reductions
-    NB = 20 if gemm_path == "generic" else 80
+    NB = {"generic": 20, "fast64": 80, "fast128": 128}[gemm_path]     # 128: the wgrad kernel's 64 x 128 tile
     Bm = rnd((B, NB, T), 46)
     dW = torch.zeros(H, NB, device=dev())
     db = torch.zeros(H, device=dev())

@@ -248,7 +248,9 @@ void launch(const ctn_gemm_nt_args& a, hipStream_t s) {
 // statistics, i.e. gLN; cumulative-norm launches and ragged shapes use the kernel above.
 // ================================================================================================
 
-template <int TM, int TN, int FK, bool BWD, int BXF>
+// CLN: the statistics are rows over frames (cumulative norm) instead of one value per batch element; every use
+// fetches the four frames of its group with one 16-byte load from a row that stays in L2.
+template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN>
 __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
                                                            const int tiles_n, const int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -348,14 +350,33 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     }
     float amean = 0.f, arstd = 1.f, ac1 = 0.f, ac2 = 0.f, bmean = 0.f, brstd = 1.f;
-    if (BWD) {
+    if (BWD && !CLN) {
         const int64_t si = (int64_t)b * a.a_ssb;
         amean = a.a_mean[si]; arstd = a.a_rstd[si]; ac1 = a.a_c1[si]; ac2 = a.a_c2[si];
     }
-    if (BXF & CTN_XF_NORM) {
+    if ((BXF & CTN_XF_NORM) && !CLN) {
         const int64_t si = (int64_t)b * a.b_ssb;
         bmean = a.b_mean[si]; brstd = a.b_rstd[si];
     }
+    const int tstat = ((a.T + 3) & ~3) - 4;               // last float4 of a statistics row
+    const float* pam = BWD ? a.a_mean + (int64_t)b * a.a_ssb : nullptr;
+    const float* par = BWD ? a.a_rstd + (int64_t)b * a.a_ssb : nullptr;
+    const float* pa1 = BWD ? a.a_c1 + (int64_t)b * a.a_ssb : nullptr;
+    const float* pa2 = BWD ? a.a_c2 + (int64_t)b * a.a_ssb : nullptr;
+    const float* pbm = (BXF & CTN_XF_NORM) ? a.b_mean + (int64_t)b * a.b_ssb : nullptr;
+    const float* pbr = (BXF & CTN_XF_NORM) ? a.b_rstd + (int64_t)b * a.b_ssb : nullptr;
+    constexpr bool BSTAT = CLN && (BXF & CTN_XF_NORM) != 0;
+    f32x4 bmv[FK / 8], brv[FK / 8];                       // cLN: B statistics of this half-wave's frame groups
+    auto load_bstat = [&](int t0) {
+        if (BSTAT) {
+#pragma unroll
+            for (int c = 0; c < FK / 8; ++c) {
+                const int tf = min(t0 + 4 * (2 * c + half), tstat);
+                bmv[c] = ctn_ld4(pbm + tf);
+                brv[c] = ctn_ld4(pbr + tf);
+            }
+        }
+    };
     // the two waves of a tile row read the same A rows: one of them reduces, and only in the first tile column
     const bool reducer = (tile_n == 0) && ((wave & 1) == 0);
     const bool do_rowsum = reducer && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr);
@@ -407,7 +428,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
                 }
                 if (BXF & CTN_XF_NORM) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[j][e] = (bv[j][e] - bmean) * brstd * bg[j] + bb[j];
+                    for (int e = 0; e < 4; ++e)
+                        bv[j][e] = BSTAT ? (bv[j][e] - bmv[c][e]) * brv[c][e] * bg[j] + bb[j]
+                                         : (bv[j][e] - bmean) * brstd * bg[j] + bb[j];
                 }
                 if (TAIL) {
 #pragma unroll
@@ -438,13 +461,18 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     for (int u = 0; u < XPT; ++u) {
         const int m = m_blk + xrow + XRP * u;
         xv[u] = m < M;
-        xg[u] = (BWD && xv[u]) ? a.a_gamma[m] * arstd : 0.f;
+        xg[u] = (BWD && xv[u]) ? a.a_gamma[m] * (CLN ? 1.f : arstd) : 0.f;
         xsum[u] = 0.f;
     }
     const bool xreduce = BWD && tile_n == 0;
     auto transform = [&](float* As, int t0) {
         float* A2s = As + FTA + FTB;
         const int tf = t0 + 4 * xgrp;
+        f32x4 am4, ar4, a14, a24;
+        if (CLN) {
+            const int ts = min(tf, tstat);
+            am4 = ctn_ld4(pam + ts); ar4 = ctn_ld4(par + ts); a14 = ctn_ld4(pa1 + ts); a24 = ctn_ld4(pa2 + ts);
+        }
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int o = (xrow + XRP * u) * FK + xslot * 4;
@@ -453,7 +481,8 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 #pragma unroll
             for (int e = 0; e < 4; ++e) {      // 8 vector ops per element: this loop is 20 % of the launch
                 const float sl = y[e] > 0.f ? 1.f : a_alpha;          // PReLU slope at y
-                const float du = xg[u] * v[e] + ac1 + (sl * y[e] - amean) * ac2;   // xg = gamma * rstd
+                const float du = CLN ? xg[u] * ar4[e] * v[e] + a14[e] + (sl * y[e] - am4[e]) * a24[e]
+                                     : xg[u] * v[e] + ac1 + (sl * y[e] - amean) * ac2;   // gLN: xg = gamma * rstd
                 const bool valid = xv[u] && (tf + e < t_end);
                 v[e] = valid ? sl * du : 0.f;
                 if (xreduce && valid && !(y[e] > 0.f)) dalpha += (double)(du * y[e]);
@@ -466,10 +495,11 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     if (!BWD) {
         if (nk > 0) issue(t_begin, 0);
         for (int kt = 0; kt < nk; ++kt) {
+            const int t0 = t_begin + kt * FK;
+            load_bstat(t0);
             // every wave's pieces of tile kt must have landed before any wave reads the tile
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const int t0 = t_begin + kt * FK;
             if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
             const float* As = lds + (kt & 1) * BUF;
             if (t0 + FK > t_end)
@@ -490,9 +520,10 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             transform(lds, t_begin);
         }
         for (int kt = 0; kt < nk; ++kt) {
+            const int t0 = t_begin + kt * FK;
+            load_bstat(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 have landed
             __syncthreads();                                     // tile kt transformed, tile kt+1 complete, tile kt-1 free
-            const int t0 = t_begin + kt * FK;
             if (kt + 2 < nk) issue(t0 + 2 * FK, (kt + 2) % 3);
             if (kt + 1 < nk) transform(lds + ((kt + 1) % 3) * BUF, t0 + FK);
             const float* As = lds + (kt % 3) * BUF;
@@ -566,10 +597,28 @@ bool fast_ok(const ctn_gemm_nt_args& a) {
     if (a.M % 16 != 0 || a.N % 16 != 0 || a.M1 % 16 != 0) return false;    // DMA pieces are 8 or 16 whole rows
     const int64_t lim = 0x40000000 / 4 - 4096;
     if ((int64_t)a.M * a.lda >= lim || (int64_t)a.M * a.ldab >= lim || (int64_t)a.N * a.ldb >= lim) return false;
-    if (a.aflags & CTN_XF_NORMBWD) {
-        if (a.a_sst != 0 || (int64_t)a.M * a.lda2 >= lim) return false;
+    // statistics: one value per batch element (stride 0) or a row over frames (stride 1, pitch % 4 == 0, aligned);
+    // both operands must use the same kind
+    auto rows_ok = [&](const float* p, int64_t sb) { return ctn_aligned16(p) && sb % 4 == 0 && sb >= ((a.T + 3) & ~3); };
+    const bool a_st = (a.aflags & CTN_XF_NORMBWD) != 0, b_st = (a.bflags & CTN_XF_NORM) != 0;
+    if (a_st) {
+        if ((int64_t)a.M * a.lda2 >= lim) return false;
+        if (a.a_sst == 1) {
+            if (!rows_ok(a.a_mean, a.a_ssb) || !rows_ok(a.a_rstd, a.a_ssb) || !rows_ok(a.a_c1, a.a_ssb) ||
+                !rows_ok(a.a_c2, a.a_ssb))
+                return false;
+        } else if (a.a_sst != 0) {
+            return false;
+        }
     }
-    if ((a.bflags & CTN_XF_NORM) && a.b_sst != 0) return false;
+    if (b_st) {
+        if (a.b_sst == 1) {
+            if (!rows_ok(a.b_mean, a.b_ssb) || !rows_ok(a.b_rstd, a.b_ssb)) return false;
+        } else if (a.b_sst != 0) {
+            return false;
+        }
+    }
+    if (a_st && b_st && a.a_sst != a.b_sst) return false;
     return true;
 }
 
@@ -580,6 +629,10 @@ bool fast_ok(const ctn_gemm_nt_args& a) {
 // transformed once, not once per tile column, and each barrier covers twice the MFMAs.
 bool wide_n(const ctn_gemm_nt_args& a) { return (a.aflags & CTN_XF_NORMBWD) && a.N % 128 == 0; }
 
+bool stat_rows(const ctn_gemm_nt_args& a) {
+    return ((a.aflags & CTN_XF_NORMBWD) && a.a_sst == 1) || ((a.bflags & CTN_XF_NORM) && a.b_sst == 1);
+}
+
 template <int TM, int TN, bool BWD, int BXF>
 void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     constexpr int FK = BWD ? 16 : 32;
@@ -588,8 +641,12 @@ void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
     const size_t tile_floats = (size_t)(TM + TN + (BWD ? TM : 0)) * FK;
     const size_t shmem = (BWD ? 3 : 2) * tile_floats * sizeof(float);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF>), dim3(total), dim3(NTH), shmem, s, a, tiles_m, tiles_n,
-                       nchunks);
+    if (stat_rows(a))
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true>), dim3(total), dim3(NTH), shmem, s, a, tiles_m,
+                           tiles_n, nchunks);
+    else
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false>), dim3(total), dim3(NTH), shmem, s, a, tiles_m,
+                           tiles_n, nchunks);
 }
 
 void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) {

@@ -276,8 +276,9 @@ def test_gemm_nt_plain(M, N, T, batch, kchunk):
     assert_close(rs, A.sum((0, 2)), TOL, "rowsum")
 
 
+@pytest.mark.parametrize("cln", [False, True])
 @pytest.mark.parametrize("fast", [False, True])
-def test_gemm_nt_split_rows_norm_b(fast):
+def test_gemm_nt_split_rows_norm_b(fast, cln):
     from speech_amd import ops
     M1, M2, N, T, B = (80, 64, 128, 301, 2) if fast else (16, 24, 40, 301, 2)   # fast: the LDS-DMA kernel's shapes
     f = lambda t: t.float().to(dev())
@@ -286,14 +287,14 @@ def test_gemm_nt_split_rows_norm_b(fast):
     alpha = torch.tensor([0.2], dtype=torch.float64)
     gamma, beta = 1 + 0.2 * rnd((N,), 55), 0.2 * rnd((N,), 56)
     u = prelu(y, alpha)
-    mean, rstd = gln_stats(u)
+    mean, rstd = (cln_stats if cln else gln_stats)(u)
     n = (u - mean) * rstd * gamma.view(1, N, 1) + beta.view(1, N, 1)
     C1 = torch.zeros(M1, N, device=dev())
     C2 = torch.zeros(M2, N, device=dev())
     r1 = torch.zeros(M1, device=dev())
     r2 = torch.zeros(M2, device=dev())
     ops.gemm_nt(M1 + M2, N, T, B, act(A1), act(y), C1, N, Ab=act(A2), M1=M1, C2=C2, ldc2=N, a_rowsum=r1, a_rowsum2=r2,
-                bflags=ops.XF_PRELU | ops.XF_NORM, b_alpha=f(alpha), b_stat=make_stat(mean, rstd, False),
+                bflags=ops.XF_PRELU | ops.XF_NORM, b_alpha=f(alpha), b_stat=make_stat(mean, rstd, cln),
                 b_gamma=f(gamma), b_beta=f(beta), kchunk=128)
     torch.cuda.synchronize()
     assert_close(C1, torch.einsum("bmt,bnt->mn", A1, n), TOL, "C1")

@@ -307,6 +307,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 #define CTN_BLDS16(rs, lp, vo, so) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
     auto issue = [&](int t0, int buf) {
+#ifdef CTN_DBG_NT_NO_LOADS
+        return;
+#endif
         float* base = lds + buf * BUF;
         const bool edge = t0 + FK > ldlim;               // uniform; true for at most the last k-tile of a row
         const int oob = edge ? RS_BYTES : 0;             // added to the offsets of lanes past the row pitch
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             bb[j] = a.b_beta[n];
         }
     }
+    constexpr bool BSTAT = CLN && (BXF & CTN_XF_NORM) != 0;
     float amean = 0.f, arstd = 1.f, ac1 = 0.f, ac2 = 0.f, bmean = 0.f, brstd = 1.f;
     if (BWD && !CLN) {
         const int64_t si = (int64_t)b * a.a_ssb;
@@ -365,7 +369,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     const float* pa2 = BWD ? a.a_c2 + (int64_t)b * a.a_ssb : nullptr;
     const float* pbm = (BXF & CTN_XF_NORM) ? a.b_mean + (int64_t)b * a.b_ssb : nullptr;
     const float* pbr = (BXF & CTN_XF_NORM) ? a.b_rstd + (int64_t)b * a.b_ssb : nullptr;
-    constexpr bool BSTAT = CLN && (BXF & CTN_XF_NORM) != 0;
+    if ((BXF & CTN_XF_NORM) && !BSTAT) {
+        // per-batch statistics: (u - mean) * rstd * gamma + beta as one fma per element, u * bg + bb
+#pragma unroll
+        for (int j = 0; j < TTN; ++j) {
+            bg[j] *= brstd;
+            bb[j] -= bmean * bg[j];
+        }
+    }
     f32x4 bmv[FK / 8], brv[FK / 8];                       // cLN: B statistics of this half-wave's frame groups
     auto load_bstat = [&](int t0) {
         if (BSTAT) {
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         bv[j][e] = BSTAT ? (bv[j][e] - bmv[c][e]) * brv[c][e] * bg[j] + bb[j]
-                                         : (bv[j][e] - bmean) * brstd * bg[j] + bb[j];
+                                         : __builtin_fmaf(bv[j][e], bg[j], bb[j]);
                 }
                 if (TAIL) {
 #pragma unroll
@@ -444,7 +455,11 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
                 for (int i = 0; i < TTM; ++i)
 #pragma unroll
                     for (int j = 0; j < TTN; ++j)
+#ifdef CTN_DBG_NT_NO_MFMA
+                        acc[i][j][e] += av[i][e] * bv[j][e];
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+#endif
         }
     };
 
@@ -492,20 +507,26 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     };
 
+    // The ragged last k-tile (at most one per block) runs after the loop as code of its own: with both forms of
+    // compute() inside the loop the compiler moves the accumulators out of and back into the AGPRs on every trip.
+    const int nfull = (t_end - t_begin) / FK;             // k-tiles that lie wholly inside the chunk
     if (!BWD) {
         if (nk > 0) issue(t_begin, 0);
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nfull; ++kt) {
             const int t0 = t_begin + kt * FK;
             load_bstat(t0);
             // every wave's pieces of tile kt must have landed before any wave reads the tile
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
-            const float* As = lds + (kt & 1) * BUF;
-            if (t0 + FK > t_end)
-                compute(As, t0, std::true_type{});
-            else
-                compute(As, t0, std::false_type{});
+            compute(lds + (kt & 1) * BUF, t0, std::false_type{});
+        }
+        if (nfull < nk) {
+            const int t0 = t_begin + nfull * FK;
+            load_bstat(t0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(lds + (nfull & 1) * BUF, t0, std::true_type{});
         }
     } else {
         // NORMBWD: ring of three buffers.  In iteration kt the waves run the MFMAs of tile kt (transformed in the
@@ -519,18 +540,21 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             if (nk > 1) issue(t_begin + FK, 1);
             transform(lds, t_begin);
         }
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nfull; ++kt) {
             const int t0 = t_begin + kt * FK;
             load_bstat(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 have landed
             __syncthreads();                                     // tile kt transformed, tile kt+1 complete, tile kt-1 free
             if (kt + 2 < nk) issue(t0 + 2 * FK, (kt + 2) % 3);
             if (kt + 1 < nk) transform(lds + ((kt + 1) % 3) * BUF, t0 + FK);
-            const float* As = lds + (kt % 3) * BUF;
-            if (t0 + FK > t_end)
-                compute(As, t0, std::true_type{});
-            else
-                compute(As, t0, std::false_type{});
+            compute(lds + (kt % 3) * BUF, t0, std::false_type{});
+        }
+        if (nfull < nk) {
+            const int t0 = t_begin + nfull * FK;
+            load_bstat(t0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                     // the ragged tile has been transformed
+            compute(lds + (nfull % 3) * BUF, t0, std::true_type{});
         }
     }
 
@@ -629,13 +653,16 @@ bool fast_ok(const ctn_gemm_nt_args& a) {
 // transformed once, not once per tile column, and each barrier covers twice the MFMAs.
 bool wide_n(const ctn_gemm_nt_args& a) { return (a.aflags & CTN_XF_NORMBWD) && a.N % 128 == 0; }
 
+// Plain / B-transform variants: 128 x 64 when M allows.  A transformed B value then feeds two MFMAs instead of one and
+// the operand bytes drawn from L2 per MFMA drop by a quarter.
+bool tall_m(const ctn_gemm_nt_args& a) { return !(a.aflags & CTN_XF_NORMBWD) && a.M % 128 == 0; }
+
 bool stat_rows(const ctn_gemm_nt_args& a) {
     return ((a.aflags & CTN_XF_NORMBWD) && a.a_sst == 1) || ((a.bflags & CTN_XF_NORM) && a.b_sst == 1);
 }
 
-template <int TM, int TN, bool BWD, int BXF>
+template <int TM, int TN, bool BWD, int BXF, int FK = (BWD ? 16 : 32)>
 void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
-    constexpr int FK = BWD ? 16 : 32;
     const int tiles_m = ctn_cdiv(a.M, TM), tiles_n = ctn_cdiv(a.N, TN);
     const int nchunks = ctn_cdiv(a.T, a.kchunk);
     const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
@@ -663,6 +690,11 @@ void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) {
             else if (bxf == CTN_XF_NORM) launch_fast_x<64, 64, true, CTN_XF_NORM>(a, s);
             else launch_fast_x<64, 64, true, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
         }
+    } else if (tall_m(a)) {
+        if (bxf == 0) launch_fast_x<128, 64, false, 0>(a, s);
+        else if (bxf == CTN_XF_PRELU) launch_fast_x<128, 64, false, CTN_XF_PRELU>(a, s);
+        else if (bxf == CTN_XF_NORM) launch_fast_x<128, 64, false, CTN_XF_NORM>(a, s);
+        else launch_fast_x<128, 64, false, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
     } else {
         if (bxf == 0) launch_fast_x<64, 64, false, 0>(a, s);
         else if (bxf == CTN_XF_PRELU) launch_fast_x<64, 64, false, CTN_XF_PRELU>(a, s);

@@ -294,11 +294,13 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
     a.a_rowsum, a.a_rowsum2, a.a_dalpha = _ptr(a_rowsum), _ptr(a_rowsum2), _ptr(a_dalpha)
     a.B, a.ldb, a.bbs = _ptr(B), B.stride(1), B.stride(0)
     a.bflags = bflags
-    # the library's wgrad kernel works on 64 x 64 output tiles, 64 x 128 for the NORMBWD variant when N allows
+    # the library's wgrad kernel works on 64 x 64 output tiles, 64 x 128 for the NORMBWD variant when N allows,
+    # 128 x 64 for the other variants when M allows
     tn = 128 if (aflags & XF_NORMBWD) and N % 128 == 0 else 64
-    tiles = ((M + 63) // 64) * ((N + tn - 1) // tn)
-    # one generation of resident blocks: 4 per CU (3 for the wide NORMBWD tile, whose ring of LDS buffers is larger)
-    a.kchunk = kchunk or pick_kchunk(T, batch, tiles, 768 if tn == 128 else 1024)
+    tm = 128 if not (aflags & XF_NORMBWD) and M % 128 == 0 else 64
+    tiles = ((M + tm - 1) // tm) * ((N + tn - 1) // tn)
+    # one generation of resident blocks: 4 per CU (3 for the 64 x 128 and 128 x 64 tiles, whose LDS buffers are larger)
+    a.kchunk = kchunk or pick_kchunk(T, batch, tiles, 768 if (tn == 128 or tm == 128) else 1024)
     a.b_alpha = _ptr(b_alpha)
     if b_stat is not None:
         a.b_mean, a.b_rstd, a.b_ssb, a.b_sst = _ptr(b_stat.mean), _ptr(b_stat.rstd), b_stat.sb, b_stat.st

@@ -88,11 +88,15 @@ def instrumented_step(trainer, mixture, sources):
     return out
 
 
+def traffic_file(batch):
+    return "profiles/r1_bench_b{}_pmc_traffic.json".format(batch)
+
+
 def profiled_traffic(prefix, batch):
     """Average HBM bytes per launch of the kernels whose name contains `prefix`, from the committed rocprofv3 PMC
     summary of this benchmark at the same per-GPU batch (counters cannot be read inside the timed process);
     None when there is no summary for this batch."""
-    path = os.path.join(ROOT, "profiles", "r1_bench_b16_pmc_traffic.json")
+    path = os.path.join(ROOT, traffic_file(batch))
     try:
         with open(path) as f:
             d = json.load(f)
@@ -134,7 +138,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch every kernel eagerly instead of replaying the forward/backward pass from a HIP graph")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches of a rank's shard run on separate HIP streams")
@@ -217,7 +221,7 @@ def main():
         roof = dict(bound="mfma", kernel="gemm_nn_fast_kernel (f32 MFMA 32x32x2, pointwise conv fwd + dgrad)",
                     achieved=round(a, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(a / PEAK_F32_MFMA_TFLOPS, 4), traffic=profiled_traffic("gemm_nn_fast_kernel", args.batch),
-                    traffic_source="profiles/r1_bench_b16_pmc_traffic.json",
+                    traffic_source=traffic_file(args.batch),
                     mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph is the profiled command)",
                     launches_per_step=gn["launches"],
                     avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1))

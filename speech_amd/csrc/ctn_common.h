@@ -41,6 +41,11 @@ __device__ __forceinline__ int ctn_slot() {
 }
 
 __device__ __forceinline__ float ctn_prelu(float v, float a) { return v > 0.f ? v : a * v; }
+// PReLU in two vector instructions for MFMA loops, where every vector slot counts: for a slope a <= 1 the result is
+// max(v, a*v), for a > 1 it is min(v, a*v); both are the median of (v, a*v, lim) with lim = +inf / -inf.  The value
+// is one of v and a*v, bit-identical to ctn_prelu.
+__device__ __forceinline__ float ctn_prelu_lim(float a) { return a <= 1.f ? __builtin_inff() : -__builtin_inff(); }
+__device__ __forceinline__ float ctn_prelu_med(float v, float a, float lim) { return __builtin_amdgcn_fmed3f(v, a * v, lim); }
 
 __device__ __forceinline__ float ctn_wave_sum(float v) {
 #pragma unroll

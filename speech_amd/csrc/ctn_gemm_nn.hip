@@ -491,6 +491,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
     }
+    // constants of the operand transforms, arranged so that the k-loop spends the fewest vector instructions:
+    //   norm:          (u - mean) * rstd * g + be          = fma(fma(u, rstd, nmr), g, be),   nmr = -mean * rstd
+    //   norm backward: g * dn * rstd + c1 + (u - mean) * c2 = fma(g * dn, rstd, fma(u, c2, c1m)), c1m = c1 - mean * c2
+    float nmr[NJ], c1m[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        nmr[j] = -mean[j] * rstd[j];
+        c1m[j] = c1[j] - mean[j] * c2[j];
+    }
+    const float plim = ctn_prelu_lim(alpha);
 
     // Tiles are fetched with buffer_load_dwordx4 ... lds: the descriptor and the k-dependent part of the address
     // (soffset) are scalar, the per-lane part (voffset) is loop-invariant, so a k-tile's loads cost no vector
@@ -592,19 +602,19 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const float y = X2s[k * FBN_ + wn0 + j * 32 + l31];
-                    const float u = ctn_prelu(y, alpha);
-                    const float du = g * bv[j] * rstd[j] + c1[j] + (u - mean[j]) * c2[j];
-                    bv[j] = y > 0.f ? du : alpha * du;
+                    const float sl = y > 0.f ? 1.f : alpha;           // PReLU slope at y
+                    const float du = __builtin_fmaf(g * bv[j], rstd[j], __builtin_fmaf(sl * y, c2[j], c1m[j]));
+                    bv[j] = sl * du;
                 }
             } else {
                 if (XF & CTN_XF_PRELU) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) bv[j] = ctn_prelu(bv[j], alpha);
+                    for (int j = 0; j < NJ; ++j) bv[j] = ctn_prelu_med(bv[j], alpha, plim);
                 }
                 if (XF & CTN_XF_NORM) {
                     const float g = Gs[k0 + k], be = Bes[k0 + k];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) bv[j] = (bv[j] - mean[j]) * rstd[j] * g + be;
+                    for (int j = 0; j < NJ; ++j) bv[j] = __builtin_fmaf(__builtin_fmaf(bv[j], rstd[j], nmr[j]), g, be);
                 }
             }
 #ifndef CTN_DBG_NO_MFMA

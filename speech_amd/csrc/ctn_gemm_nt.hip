@@ -342,6 +342,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     // per-lane row constants
     const float a_alpha = a.a_alpha ? a.a_alpha[0] : 1.f;
     const float b_alpha = a.b_alpha ? a.b_alpha[0] : 1.f;
+    const float bplim = ctn_prelu_lim(b_alpha);
     float bg[TTN], bb[TTN];
 #pragma unroll
     for (int j = 0; j < TTN; ++j) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             for (int j = 0; j < TTN; ++j) {
                 if (BXF & CTN_XF_PRELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[j][e] = ctn_prelu(bv[j][e], b_alpha);
+                    for (int e = 0; e < 4; ++e) bv[j][e] = ctn_prelu_med(bv[j][e], b_alpha, bplim);
                 }
                 if (BXF & CTN_XF_NORM) {
 #pragma unroll
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         xsum[u] = 0.f;
     }
     const bool xreduce = BWD && tile_n == 0;
+    const float ac1m = ac1 - amean * ac2;               // gLN: c1 + (u - mean) * c2 = fma(u, c2, ac1m)
     auto transform = [&](float* As, int t0) {
         float* A2s = As + FTA + FTB;
         const int tf = t0 + 4 * xgrp;
@@ -493,15 +495,17 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
             const int o = (xrow + XRP * u) * FK + xslot * 4;
             f32x4 v = ctn_ld4(&As[o]);
             const f32x4 y = ctn_ld4(&A2s[o]);
+            float da4 = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {      // 8 vector ops per element: this loop is 20 % of the launch
                 const float sl = y[e] > 0.f ? 1.f : a_alpha;          // PReLU slope at y
                 const float du = CLN ? xg[u] * ar4[e] * v[e] + a14[e] + (sl * y[e] - am4[e]) * a24[e]
-                                     : xg[u] * v[e] + ac1 + (sl * y[e] - amean) * ac2;   // gLN: xg = gamma * rstd
+                                     : __builtin_fmaf(xg[u], v[e], __builtin_fmaf(sl * y[e], ac2, ac1m));   // xg = gamma * rstd
                 const bool valid = xv[u] && (tf + e < t_end);
                 v[e] = valid ? sl * du : 0.f;
-                if (xreduce && valid && !(y[e] > 0.f)) dalpha += (double)(du * y[e]);
+                if (xreduce && valid && !(y[e] > 0.f)) da4 += du * y[e];
             }
+            if (xreduce) dalpha += (double)da4;    // 4 terms in fp32, the hundreds of signed terms above them in fp64
             if (xreduce) xsum[u] += (v[0] + v[1]) + (v[2] + v[3]);
             ctn_st4(&As[o], v);
         }
@@ -669,11 +673,11 @@ void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const size_t tile_floats = (size_t)(TM + TN + (BWD ? TM : 0)) * FK;
     const size_t shmem = (BWD ? 3 : 2) * tile_floats * sizeof(float);
     if (stat_rows(a))
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true>), dim3(total), dim3(NTH), shmem, s, a, tiles_m,
-                           tiles_n, nchunks);
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true>), dim3(total), dim3(NTH), shmem, s, a,
+                           tiles_m, tiles_n, nchunks);
     else
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false>), dim3(total), dim3(NTH), shmem, s, a, tiles_m,
-                           tiles_n, nchunks);
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false>), dim3(total), dim3(NTH), shmem, s, a,
+                           tiles_m, tiles_n, nchunks);
 }
 
 void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) {

@@ -82,7 +82,7 @@ class FlatTrainer:
                 view = self.flat_p[off:off + p.numel()].view(p.shape)
                 view.copy_(p)
                 p.data = view                      # parameters become views of the flat buffer
-        self.params = params
+        self.params, self.offsets = params, offsets
         self.flat_g = torch.zeros_like(self.flat_p)
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
@@ -90,6 +90,11 @@ class FlatTrainer:
         self.step_count = 0
         if self.world > 1:                         # identical replicas: broadcast rank 0's weights
             dist.broadcast(self.flat_p, src=0, group=self.group)
+
+    def moment_views(self):
+        """{id(parameter): (exp_avg, exp_avg_sq)} as views of the flat Adam buffers, shaped like the parameter."""
+        return {id(p): (self.m[off:off + p.numel()].view(p.shape), self.v[off:off + p.numel()].view(p.shape))
+                for p, off in zip(self.params, self.offsets)}
 
     def forward_backward(self, mixture, sources):
         """Fills self.flat_g with this rank's gradient of the shard-mean loss; returns (loss, perm).

@@ -123,3 +123,29 @@ def test_resume_from_own_checkpoint_equals_uninterrupted_run(tmp_path, mode, tol
     assert_close(c.valid_loss, a.valid_loss, tol, "valid loss history")
     assert_close(c.flat.flat_p, a.flat.flat_p, tol, "parameters")
     assert_close(c.flat.m, a.flat.m, 10 * tol, "exp_avg")
+
+
+def test_prefetcher_feeds_the_epoch_loop_from_wave_files(tmp_path):
+    """wave files -> WaveTrainDataset / WaveEvalDataset -> loaders -> DevicePrefetcher -> TrainerBase: the batches that
+    arrive on the GPU are the loader's, in order, and an epoch over them runs."""
+    import dataset_cases as cases
+    from speech_amd import dataset as D
+    wav_root, list_path = cases.write_corpus(str(tmp_path))
+    train = D.TrainDataLoader(D.WaveTrainDataset(wav_root, list_path, samples=8000, overlap=0), batch_size=4, shuffle=False,
+                              drop_last=True)
+    valid = D.EvalDataLoader(D.WaveEvalDataset(wav_root, list_path, max_samples=8000), batch_size=1, shuffle=False)
+    dev = torch.device("cuda:0")
+    pre = D.DevicePrefetcher(train, dev, depth=2)
+    assert len(pre) == len(train) and pre.dataset is train.dataset
+    n = 0
+    for (gm, gs), (cm, cs) in zip(pre, train):
+        assert gm.device.type == "cuda" and torch.equal(gm.cpu(), cm) and torch.equal(gs.cpu(), cs)
+        n += 1
+    assert n == len(train)
+    for _ in pre:                     # abandoning the iteration early must not hang the worker
+        break
+    tr = make_trainer(os.path.join(str(tmp_path), "run"), 1)
+    tr.train_loader, tr.valid_loader = pre, D.DevicePrefetcher(valid, dev)
+    tr.run()
+    assert torch.isfinite(tr.train_loss).all() and torch.isfinite(tr.valid_loss).all()
+    assert tr.flat.step_count == len(train)

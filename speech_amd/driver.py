@@ -6,8 +6,7 @@ recipe's `AdhocTrainer`, egs/wsj0-mix/conv-tasnet/src/adhoc_driver.py:7-44): sam
 side resumes on the other.  What differs is underneath: the optimizer step is the fused clip + Adam kernel of
 `FlatTrainer` on flat buffers, the `torch.optim.Adam` object the caller passes in supplies the hyper-parameters,
 carries the learning rate (the schedule halves `param_groups[...]['lr']` exactly as the reference does) and gives
-the checkpoint its `optim_dict` layout.  Wave files of validation samples and the loss plot
-(driver.py:185-202, :120-121) are not written: there is no audio I/O in this package.
+the checkpoint its `optim_dict` layout.  The loss plot (driver.py:120-121) is not drawn: no plotting dependency here.
 """
 import os
 import time
@@ -16,7 +15,10 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
+from .dataset import save_wav
 from .trainer import FlatTrainer
+
+BITS_PER_SAMPLE_WSJ0 = 16
 
 
 class EpochControl:
@@ -236,15 +238,31 @@ class TrainerBase:
         n_valid = len(self.valid_loader.dataset)
         with torch.no_grad():
             for idx, batch in enumerate(self.valid_loader):
-                mixture, sources = batch[0].to(dev), batch[1].to(dev)       # batch[2]: segment IDs, unused here
+                mixture, sources = batch[0].to(dev), batch[1].to(dev)
                 output = self.model(mixture)
                 loss, _ = self.pit_criterion(output, sources, batch_mean=False)
                 total += loss.sum(dim=0).double()
+                if idx < 5 and self.rank == 0 and len(batch) > 2:
+                    self.save_samples(epoch, batch[2][0], mixture[0].squeeze(dim=0).cpu(), output[0].cpu())
         n = torch.tensor(float(n_valid), device=dev, dtype=torch.float64)
         if self.flat.world > 1:               # every rank validates its own part of the set
             dist.all_reduce(total, group=self.flat.group)
             dist.all_reduce(n, group=self.flat.group)
         return (total / n).item()
+
+    def save_samples(self, epoch, segment_ID, mixture, estimated_sources):
+        """driver.py:185-202: the first five validation mixtures and their estimates, peak-normalised, as 16-bit
+        wave files under sample_dir/<segment ID>/."""
+        save_dir = os.path.join(self.sample_dir, segment_ID)
+        os.makedirs(save_dir, exist_ok=True)
+        mixture = mixture / torch.abs(mixture).max()
+        save_wav(os.path.join(save_dir, "mixture.wav"), mixture.unsqueeze(dim=0) if mixture.dim() == 1 else mixture,
+                 self.sample_rate, bits_per_sample=BITS_PER_SAMPLE_WSJ0)
+        for source_idx, estimated_source in enumerate(estimated_sources):
+            estimated_source = estimated_source / torch.abs(estimated_source).max()
+            signal = estimated_source.unsqueeze(dim=0) if estimated_source.dim() == 1 else estimated_source
+            save_wav(os.path.join(save_dir, "epoch{}-{}.wav".format(epoch + 1, source_idx + 1)), signal, self.sample_rate,
+                     bits_per_sample=BITS_PER_SAMPLE_WSJ0)
 
     def save_model(self, epoch, model_path='./tmp.pth'):
         """driver.py:208-226: the model's config, its state_dict, the optimizer's state_dict and the loss history."""

@@ -149,3 +149,8 @@ def test_prefetcher_feeds_the_epoch_loop_from_wave_files(tmp_path):
     tr.run()
     assert torch.isfinite(tr.train_loss).all() and torch.isfinite(tr.valid_loss).all()
     assert tr.flat.step_count == len(train)
+    # validation samples of the first utterances, as the reference writes them (driver.py:185-202)
+    sample = os.path.join(str(tmp_path), "run", "sample", "utt_a")
+    assert sorted(os.listdir(sample)) == ["epoch1-1.wav", "epoch1-2.wav", "mixture.wav"]
+    w, rate = D.load_wav(os.path.join(sample, "epoch1-1.wav"))
+    assert rate == 8000 and tuple(w.shape) == (1, 8000) and abs(float(w.abs().max()) - 1.0) < 1e-3

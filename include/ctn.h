@@ -80,6 +80,19 @@ int ctn_gemm_nn_set_tile(int width);
  * (M_out, K_in) out k-major for ctn_gemm_nn. */
 int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64_t coff, void* stream);
 
+/* Chunking for dual-path separators and its adjoint.
+ * ctn_segment: y[b][c][s][k] = xpad[b][c][s*P + k] with y dense (batch, C, S, K) and xpad = x (rows of T frames, pitch
+ * ldx, batch stride xbs) zero-padded by pad_left frames in front and as far as the S chunks reach behind.  Replaces
+ * Segment1d.forward (src/models/transform.py:15-31: F.unfold + permute) together with the F.pad in front of it
+ * (src/models/dprnn_tasnet.py:335-341); pad_left = 0 and S = (T-K)/P+1 give Segment1d alone.
+ * ctn_overlap_add: x[b][c][t] = sum over s of y[b][c][s][t + pad_left - s*P] for t < T.  Replaces OverlapAdd1d.forward
+ * (transform.py:45-61: permute + F.fold) together with the trimming F.pad behind it (dprnn_tasnet.py:343-344).
+ * Each is the other's backward. */
+int ctn_segment(const float* x, int64_t xbs, int64_t ldx, int batch, int C, int T, int pad_left, int K, int P, int S,
+                float* y, void* stream);
+int ctn_overlap_add(const float* y, int batch, int C, int S, int K, int P, int pad_left, int T, float* x, int64_t xbs,
+                    int64_t ldx, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Pointwise (1x1) convolution as a batched GEMM on f32 MFMA:  Y[b] = A^T-layout(W) . xform(X[b])
  * Replaces nn.Conv1d(kernel_size=1) at src/models/conv_tasnet.py:335,341 (:371,:374) and

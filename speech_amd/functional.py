@@ -258,6 +258,39 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dgamma.view(gamma.shape), dbeta.view(beta.shape), None, None
 
 
+# ------------------------------------------------------------------------------------------------ chunking
+class SegmentFn(torch.autograd.Function):
+    """Segment1d.forward (src/models/transform.py:15-31) of the input zero-padded by (pad_left, as far as S chunks reach):
+    (B, C, T) -> (B, C, S, K).  Backward is the overlap-add of the gradient, trimmed to T."""
+
+    @staticmethod
+    def forward(ctx, x, chunk_size, hop_size, S, pad_left):
+        x = as_act(x.detach().float())
+        ctx.meta = (hop_size, x.shape[2], pad_left)
+        return ops.segment(x, chunk_size, hop_size, S, pad_left)
+
+    @staticmethod
+    def backward(ctx, dy):
+        hop_size, T, pad_left = ctx.meta
+        return ops.overlap_add(dy.contiguous().float(), hop_size, T, pad_left), None, None, None, None
+
+
+class OverlapAddFn(torch.autograd.Function):
+    """OverlapAdd1d.forward (src/models/transform.py:45-61) followed by a trim of pad_left frames in front and of
+    everything beyond T frames: (B, C, S, K) -> (B, C, T).  Backward is the segmentation of the gradient."""
+
+    @staticmethod
+    def forward(ctx, y, hop_size, T, pad_left):
+        y = y.detach().contiguous().float()
+        ctx.meta = (hop_size, y.shape[2], y.shape[3], pad_left)
+        return ops.overlap_add(y, hop_size, T, pad_left)
+
+    @staticmethod
+    def backward(ctx, dx):
+        hop_size, S, K, pad_left = ctx.meta
+        return ops.segment(as_act(dx.float()), K, hop_size, S, pad_left), None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ pointwise conv
 class Conv1x1Fn(torch.autograd.Function):
     """nn.Conv1d(C_in, C_out, kernel_size=1) forward/backward on the MFMA GEMMs."""

@@ -146,6 +146,31 @@ class Accum:
             self.sums = zeros((B, _lib.STAT_SLOTS, 2), device, torch.float64)
 
 
+# ------------------------------------------------------------------------------------------------ chunking
+def segment(x, K, P, S, pad_left=0):
+    """(B, C, T) -> dense (B, C, S, K): chunk s holds frames s*P .. s*P+K-1 of x zero-padded by pad_left in front."""
+    lib = _lib.load()
+    _require_cuda(x)
+    B, Cc, T = x.shape
+    assert x.stride(2) == 1
+    y = torch.empty((B, Cc, S, K), device=x.device, dtype=torch.float32)
+    _lib.check(lib.ctn_segment(_ptr(x), x.stride(0), x.stride(1), B, Cc, T, pad_left, K, P, S, _ptr(y), _stream()),
+               "ctn_segment")
+    return y
+
+
+def overlap_add(y, P, T, pad_left=0):
+    """dense (B, C, S, K) -> activation (B, C, T): frame t sums the chunk entries that cover padded position t + pad_left."""
+    lib = _lib.load()
+    _require_cuda(y)
+    B, Cc, S, K = y.shape
+    assert y.is_contiguous()
+    x = new_act(B, Cc, T, y.device)
+    _lib.check(lib.ctn_overlap_add(_ptr(y), B, Cc, S, K, P, pad_left, T, _ptr(x), x.stride(0), x.stride(1), _stream()),
+               "ctn_overlap_add")
+    return x
+
+
 # ------------------------------------------------------------------------------------------------ norms
 def transpose(src2d, dst, ldd, coff=0):
     lib = _lib.load()

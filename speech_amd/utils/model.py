@@ -1,4 +1,4 @@
-"""Activation factory with the reference's interface (src/utils/model.py:3-20)."""
+"""Activation and RNN factories with the reference's interface (src/utils/model.py:3-32)."""
 import torch.nn as nn
 
 
@@ -19,3 +19,15 @@ def choose_nonlinear(name, **kwargs):
     else:
         raise NotImplementedError("Invalid nonlinear function is specified. Choose 'relu' instead of {}.".format(name))
     return nonlinear
+
+
+def choose_rnn(name, **kwargs):
+    if name == 'rnn':
+        rnn = nn.RNN(**kwargs)
+    elif name == 'lstm':
+        rnn = nn.LSTM(**kwargs)
+    elif name == 'gru':
+        rnn = nn.GRU(**kwargs)
+    else:
+        raise NotImplementedError("Invalid RNN is specified. Choose 'rnn', 'lstm', or 'gru' instead of {}.".format(name))
+    return rnn

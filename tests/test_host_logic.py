@@ -184,3 +184,21 @@ def test_flat_layout_is_aligned_and_disjoint():
         assert off % FLAT_ALIGN == 0 and off >= end
         end = off + p.numel()
     assert total >= end and total % FLAT_ALIGN == 0
+
+
+def test_dprnn_tasnet_surface_matches_reference(golden):
+    """state_dict keys, parameter count and config of DPRNN-TasNet against what the reference's model reported."""
+    import dprnn_cases
+    from speech_amd.models.dprnn_tasnet import DPRNNTasNet
+    g = golden("dprnn")
+    for name, (cfg, _, _) in dprnn_cases.E2E.items():
+        m = DPRNNTasNet(**cfg)
+        assert list(m.state_dict().keys()) == g[name + "_keys"].tolist()
+        assert m.num_parameters == int(g[name + "_nparams"])
+        c = m.get_config()
+        for key in ("sep_chunk_size", "sep_hop_size", "sep_num_blocks", "rnn_type", "causal", "n_sources"):
+            assert key in c
+    with pytest.raises(ValueError):
+        DPRNNTasNet(**dict(dprnn_cases.SMALL, mask_nonlinear="tanh"))
+    with pytest.raises(ValueError):
+        DPRNNTasNet(**dict(dprnn_cases.SMALL, causal=False))(torch.zeros(3, 10))

@@ -112,6 +112,23 @@ def profiled_traffic(prefix, batch):
     return round(tot / n) if n else None
 
 
+def device_copy_rate(device, mbytes=1024, reps=10):
+    """GB/s (read + write) of a plain device-to-device copy of a buffer larger than the last-level cache: what a
+    streaming kernel reaches on this GPU, reported beside the nominal HBM peak."""
+    n = mbytes * 1024 * 1024 // 4
+    x = torch.empty(n, device=device, dtype=torch.float32).normal_()
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(cfg, steps=3, batch=2):
     """The oracle's training step (same arithmetic as the reference's loop) on the host CPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -230,6 +247,7 @@ def main():
                                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                                        frac=round(b / PEAK_F32_MFMA_TFLOPS, 4), launches_per_step=gt["launches"],
                                        avg_launch_us=round(gt["ms"] * 1e3 / gt["launches"], 1))
+        copy_gbs = device_copy_rate(device)
         hb = []
         for name in ("dw_fwd", "dw_bwd"):
             d = prof[name]
@@ -237,7 +255,8 @@ def main():
             hb.append(dict(bound="hbm", kernel=name + "_kernel", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
                            unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
                            traffic=profiled_traffic(name, args.batch),
-                           launches_per_step=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 1)))
+                           launches_per_step=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 1),
+                           device_copy_rate=round(copy_gbs, 1), frac_of_copy_rate=round(gbs / copy_gbs, 4)))
         roof_hbm = hb
         step_ms = dt / args.steps * 1e3
         extra["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof.items()}

@@ -13,6 +13,8 @@
 //   D: column j = l & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * h for accumulator register r in [0, 16).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ctn_common.h"
 
 namespace {
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (has_norm) {
         for (int k = tid; k < Kp; k += NTH) {
             Gs[k] = k < K ? a.gamma[k] : 0.f;
-            Bes[k] = (!BWD && k < K) ? a.beta[k] : 0.f;
+            if (!BWD) Bes[k] = k < K ? a.beta[k] : 0.f;      // (the norm-backward variant has no beta row)
         }
     }
     if (tid < FBM) {              // epilogue row constants of this tile: bias and (NORMBWD epilogue) gamma
@@ -819,9 +821,22 @@ bool fast_ok(const ctn_gemm_nn_args& a) {
     return true;
 }
 
+// Dynamic LDS of one block of the fast kernel: two buffers of operand tiles (three tiles with the norm-backward operand),
+// the gamma / beta rows of the operand transform, and at least the epilogue's staging area.
+size_t fast_lds_bytes(const ctn_gemm_nn_args& a, int width) {
+    const int Kp = ctn_cdiv(a.K, FBK) * FBK;
+    const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
+    const size_t buf = (size_t)(FBK * FBM + FBK * width + (bwd ? FBK * width : 0));
+    size_t floats = 2 * buf + (bwd ? 1 : 2) * (size_t)Kp;               // gamma row, and beta for the forward norm
+    if (floats < (size_t)64 * width) floats = (size_t)64 * width;      // epilogue staging
+    return floats * sizeof(float);
+}
+
 // Tile width: ctn_gemm_nn_set_tile() or CTN_GEMM_FBN=64|128 forces one (tuning aids).  Otherwise the width whose
-// blocks fill whole generations of the chip's 4-blocks-per-CU slots best (all blocks of a launch take the same
-// time, so a partly filled last generation is pure tail); the wide tile wins ties, it re-reads less.
+// blocks fill whole generations of the chip's block slots best (all blocks of a launch take the same time, so a
+// partly filled last generation is pure tail); the wide tile wins ties, it re-reads less.  Slots per CU: 4 by
+// registers, fewer when a width's LDS footprint does not fit four times into the CU's 160 KB (the wide tile with
+// the norm-backward operand: 3).
 int g_forced_fbn = -1;
 int pick_fbn(const ctn_gemm_nn_args& a) {
     if (g_forced_fbn < 0) {
@@ -831,17 +846,23 @@ int pick_fbn(const ctn_gemm_nn_args& a) {
     }
     if (g_forced_fbn) return g_forced_fbn;
     if (a.tile_width == 64 || a.tile_width == 128) return a.tile_width;
-    static const int slots = [] {
-        int dev = 0, cus = 0;
+    static const int cus = [] {
+        int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return 4 * cus;
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
     }();
-    auto fill = [](int64_t blocks) { return (double)blocks / (double)((blocks + slots - 1) / slots * slots); };
-    const int64_t rows = (int64_t)ctn_cdiv(a.M, FBM) * a.batch;
-    const double f128 = fill(rows * ctn_cdiv(a.T, 128)), f64 = fill(rows * ctn_cdiv(a.T, 64));
-    return f128 >= f64 - 0.02 ? 128 : 64;
+    constexpr size_t LDS_PER_CU = 160 * 1024, LDS_STATIC = 1280;   // static arrays of the kernel, rounded up
+    auto fill = [&](int width) {
+        const int64_t blocks = (int64_t)ctn_cdiv(a.M, FBM) * a.batch * ctn_cdiv(a.T, width);
+        const int per_cu = std::max((int)std::min<size_t>(4, LDS_PER_CU / (fast_lds_bytes(a, width) + LDS_STATIC)), 1);
+        const int64_t slots = (int64_t)cus * per_cu;
+        // fewer resident blocks also hide less latency: measured, the wide norm-backward tile at 2 blocks per CU
+        // is 12 % slower than the narrow one at 4 with both filling their generations
+        return (double)blocks / (double)((blocks + slots - 1) / slots * slots) * (0.5 + 0.125 * per_cu);
+    };
+    return fill(128) >= fill(64) - 0.02 ? 128 : 64;
 }
 
 template <int FBN_>
@@ -852,12 +873,8 @@ int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
         ctn_set_error("ctn_gemm_nn: grid too large");
         return CTN_ERR_ARG;
     }
-    const int Kp = ctn_cdiv(a.K, FBK) * FBK;
     const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
-    const size_t buf = (size_t)(FBK * FBM + FBK * FBN_ + (bwd ? FBK * FBN_ : 0));
-    size_t floats = 2 * buf + 2 * (size_t)Kp;
-    if (floats < 64 * FBN_) floats = 64 * FBN_;      // epilogue staging
-    const size_t shmem = floats * sizeof(float);
+    const size_t shmem = fast_lds_bytes(a, FBN_);
     const dim3 grid((unsigned)total), block(NTH);
     if (bwd) {
         hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true>), grid, block, shmem, s, a, tiles_m, tiles_n);

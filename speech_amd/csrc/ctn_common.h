@@ -93,6 +93,11 @@ __device__ __forceinline__ double ctn_block_sum_f64(double v, double* smem) {
 
 __device__ __forceinline__ f32x4 ctn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void ctn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// streaming variants (touched once by this kernel): non-temporal hint, the lines do not displace reusable data in L2
+__device__ __forceinline__ f32x4 ctn_ld4_nt(const float* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+__device__ __forceinline__ void ctn_st4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 
 // Per-frame statistics of 4 consecutive frames starting at t (gLN: stride 0 -> one value).
 struct Stat4 {

@@ -9,6 +9,16 @@
 // activation crosses HBM exactly once in each direction.
 #include "ctn_common.h"
 
+// Activations stream through these kernels once: non-temporal loads and stores (4 % on the forward, 2 % on the backward
+// kernel in the training step).  -DCTN_DBG_DW_TEMPORAL restores plain accesses for comparison.
+#if defined(CTN_DBG_DW_TEMPORAL)
+#define CTN_DW_LD ctn_ld4
+#define CTN_DW_ST ctn_st4
+#else
+#define CTN_DW_LD ctn_ld4_nt
+#define CTN_DW_ST ctn_st4_nt
+#endif
+
 namespace {
 
 constexpr int NTH = 256;
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
                 const int i4 = r0 + tid + j * NTH;
                 const int t = tA + 4 * i4;
                 v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i4 < lw4 && t >= 0 && t < T) v[j] = ctn_ld4(xrow + t);
+                if (i4 < lw4 && t >= 0 && t < T) v[j] = CTN_DW_LD(xrow + t);
             }
 #pragma unroll
             for (int j = 0; j < NIT; ++j) {
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
                     o += w[k] * x4;
                 }
             }
-            ctn_st4(yrow + t, o);
+            CTN_DW_ST(yrow + t, o);
             if (do_stats) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -213,9 +223,9 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
                 const int t = tA + 4 * i4;
                 vdn[j] = vx[j] = vy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (i4 < lw4 && t >= 0 && t < T) {
-                    vdn[j] = ctn_ld4(dnrow + t);
-                    vx[j] = ctn_ld4(xrow + t);
-                    if (obwd) vy[j] = ctn_ld4(y2row + t);
+                    vdn[j] = CTN_DW_LD(dnrow + t);
+                    vx[j] = CTN_DW_LD(xrow + t);
+                    if (obwd) vy[j] = CTN_DW_LD(y2row + t);
                 }
             }
 #pragma unroll
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
                     }
                 }
             }
-            ctn_st4(dxrow + t, o);
+            CTN_DW_ST(dxrow + t, o);
         }
         // ---- per-channel reductions
         float v[NV];
@@ -374,9 +384,9 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_kernel(const ctn_dw_bwd_args a
 #pragma unroll
     for (int j = 0; j < GIT; ++j) {
         const int tq = min(4 * (tid + j * NTH), ldmin - 4);
-        vdn[j] = ctn_ld4(dnrow + tq);
-        vy[j] = ctn_ld4(y2row + tq);
-        vx[j] = ctn_ld4(xrow + tq);
+        vdn[j] = CTN_DW_LD(dnrow + tq);
+        vy[j] = CTN_DW_LD(y2row + tq);
+        vx[j] = CTN_DW_LD(xrow + tq);
     }
     const float a1 = a.alpha1[0], a2 = a.alpha2[0];
     const float m2 = a.mean2[(int64_t)b * a.ssb2], r2 = a.rstd2[(int64_t)b * a.ssb2];
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_kernel(const ctn_dw_bwd_args a
                     s2 += g * xh4[e];
                 }
             }
-            ctn_st4(dxrow + t, o);
+            CTN_DW_ST(dxrow + t, o);
         }
     }
     float v[NV];

@@ -1,7 +1,7 @@
 """Module-level parity on the GPU: the drop-in modules (HIP kernels underneath) against the golden vectors
 the reference produced (tests/golden) and against the CPU oracle on the same seeded inputs.
 
-Tolerances: rel 1e-4 on waveforms, loss and gradients (the bar BASELINE.json states), permutation indices
+Tolerances: rel 1e-4 on waveforms, loss and gradients (the bar set for this path), permutation indices
 bit-exact."""
 import numpy as np
 import pytest

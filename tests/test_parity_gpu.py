@@ -328,3 +328,37 @@ def test_paper_backward_is_reproducible():
         for k, v in grads.items():
             scale = float(first[k].abs().max()) + 1e-30
             assert float((v - first[k]).abs().max()) <= 2e-5 * scale, "run %d differs in %s" % (run, k)
+
+
+@pytest.mark.parametrize("cfg_name,batch,T", [
+    ("small", 1, 16),         # a single frame: T equals the encoder's kernel size
+    ("small", 3, 27),         # two frames after padding 5 samples (3 left, 2 right... as conv_tasnet.py:145-147 splits it)
+    ("small", 2, 1001),       # odd length, frames not a multiple of 4
+    ("small", 1, 80000),      # 10 s: 9999 frames, rows longer than the one-block depthwise backward handles
+    ("small_causal3", 2, 1001),
+    ("small_causal3", 1, 40000),
+])
+def test_ragged_minimal_and_long_inputs_vs_float64(cfg_name, batch, T):
+    """Shapes the fixtures do not hold, against a float64 run of the oracle on the kink-free network (PReLU slopes 1),
+    so waveforms, loss and every gradient are held to the strict bar."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    cfg = O.CONFIG_SMALL if cfg_name == "small" else dict(O.CONFIG_SMALL, causal=True, n_sources=3)
+    sd = cases.e2e_state(cfg)
+    for k in sd:
+        if k.endswith("nonlinear1d.weight") or k.endswith("prelu.weight"):
+            sd[k].fill_(1.0)
+    mixture, sources = cases.e2e_batch(cfg, batch, T, 11)
+    loss64, perm64, out64, g64 = O.loss_and_grads(mixture.double(), sources.double(), {k: v.double() for k, v in sd.items()},
+                                                  cfg)
+    model = load_state(build(cfg), sd)
+    out = model(mixture.to(dev()))
+    assert tuple(out.shape) == (batch, cfg["n_sources"], T)
+    loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(perm.cpu(), perm64)
+    assert_close(out, out64, TOL, "out")
+    assert_close(loss.reshape(1), loss64.reshape(1), TOL, "loss")
+    for k, p in model.named_parameters():
+        assert_close(p.grad, g64[k], 3e-4 if p.numel() == 1 else TOL, "grad " + k)

@@ -168,6 +168,115 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
     }
 }
 
+// ------------------------------------------------------------------------------------------ forward, cLN
+// Cumulative norm: the statistics of the output are per-frame sums over ALL channels, so a block walks CG channels of
+// one time tile (TT <= 4 * NTH frames: one float4 of output per thread and channel) and keeps the per-frame sums in
+// registers, one atomic pair per frame and block at the end.  Unlike the kernel above, which stages one row per
+// barrier pair, CS rows are staged at once: CS times the loads in flight and a CS-th of the barriers -- per-frame
+// statistics make a row tile short (1024 frames + halo), and one such row per phase leaves the memory pipe idle.
+template <int CS>
+__global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a, const int CG, const int TT,
+                                                         const int lw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // CS rows of lw floats
+    const int b = blockIdx.z, c0 = blockIdx.y * CG, t0 = blockIdx.x * TT;
+    const int T = a.T, P = a.P, d = a.dilation, padL = a.pad_left;
+    const int tA = floor4(t0 - padL);
+    const int tid = threadIdx.x;
+    const float ain = a.alpha_in ? a.alpha_in[0] : 1.f;
+    const float aout = a.alpha_out ? a.alpha_out[0] : 1.f;
+    const bool do_stats = a.ecol != nullptr;
+    const bool norm = (a.xflags & CTN_XF_NORM) != 0;
+    const bool prelu_in = (a.xflags & CTN_XF_PRELU) != 0;
+    const int cend = min(c0 + CG, a.C);
+    const int t_end = min(t0 + TT, T);
+    const int lw4 = lw / 4;
+    const int items = CS * lw4;                       // float4s to stage per phase
+    constexpr int NITC = 6;                           // CS * (4 * NTH + halo + 8) / 4 <= NITC * NTH for halos <= 500
+    const int tl4 = ((T + 3) & ~3) - 4;               // last whole float4 of a row
+    const float* mrow = norm ? a.mean + (int64_t)b * a.ssb : nullptr;
+    const float* rrow = norm ? a.rstd + (int64_t)b * a.ssb : nullptr;
+
+    float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
+    const int t = t0 + 4 * tid;                       // this thread's output frames
+    for (int cg = c0; cg < cend; cg += CS) {
+        // ---- stage CS transformed, zero-padded rows; every load is issued before any is used
+        f32x4 v[NITC];
+        int rr[NITC], ii[NITC];
+#pragma unroll
+        for (int j = 0; j < NITC; ++j) {
+            const int idx = tid + j * NTH;
+            const int r = idx / lw4, i4 = idx - r * lw4;
+            rr[j] = r, ii[j] = i4;
+            const int c = min(cg + r, cend - 1);
+            const int tt = min(max(tA + 4 * i4, 0), tl4);
+            v[j] = CTN_DW_LD(a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx + tt);
+        }
+#pragma unroll
+        for (int j = 0; j < NITC; ++j) {
+            const int idx = tid + j * NTH;
+            if (idx >= items) continue;
+            const int r = rr[j], i4 = ii[j];
+            const int c = cg + r;
+            const int tt = tA + 4 * i4;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (c < cend && tt >= 0 && tt < T) {
+                float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
+                float g = 1.f, be = 0.f;
+                if (norm) {
+                    stat4(mrow, 0, a.sst, 0, tt, T, mrow[0], mu);
+                    stat4(rrow, 0, a.sst, 0, tt, T, rrow[0], rs);
+                    g = a.gamma[c], be = a.beta[c];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u = v[j][e];
+                    if (prelu_in) u = ctn_prelu(u, ain);
+                    if (norm) u = (u - mu[e]) * rs[e] * g + be;
+                    o[e] = (tt + e < T) ? u : 0.f;
+                }
+            }
+            ctn_st4(&lds[r * lw + 4 * i4], o);
+        }
+        __syncthreads();
+        // ---- taps: one float4 of output per thread and channel
+        if (t < t_end) {
+            const int base = t - padL - tA;
+#pragma unroll
+            for (int r = 0; r < CS; ++r) {
+                const int c = cg + r;
+                if (c >= cend) break;
+                const float bias = a.bias ? a.bias[c] : 0.f;
+                f32x4 o = {bias, bias, bias, bias};
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) {
+                    if (k < P) {
+                        const float wk = a.w[(int64_t)c * P + k];
+                        o += wk * lds_read4(lds + r * lw, base + k * d);
+                    }
+                }
+                CTN_DW_ST(a.y + (int64_t)b * a.ybs + (int64_t)c * a.ldy + t, o);
+                if (do_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = (t + e < T) ? ctn_prelu(o[e], aout) : 0.f;
+                        cs1[e] += u;
+                        cs2[e] += u * u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (do_stats && t < t_end) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t + e < T) {
+                atomicAdd(a.ecol + ((int64_t)b * 2 + 0) * a.ecol_ld + t + e, cs1[e]);
+                atomicAdd(a.ecol + ((int64_t)b * 2 + 1) * a.ecol_ld + t + e, cs2[e]);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ backward
 // LDS rows (same indexing, origin tA, halo H on both sides):
 //   D [i] = dy2[tA + i]   (gradient w.r.t. the conv output, after the output-side norm/PReLU backward)
@@ -518,6 +627,14 @@ int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream) {
     int CG, TT, lw;
     pick_tile(a.T, (a.P - 1) * a.dilation, a.cln != 0, 1, &CG, &TT, &lw);
     CTN_REQUIRE((size_t)lw * 4 <= 64 * 1024, "ctn_dw_fwd: dilation halo too large for LDS");
+    constexpr int CS = 4;                               // rows staged at once by the cLN kernel
+    if (a.cln && stats && (a.P - 1) * a.dilation <= 500 && (!(a.xflags & CTN_XF_NORM) || a.sst == 1)) {
+        CG = 16;
+        dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
+        hipLaunchKernelGGL(dw_fwd_cln_kernel<CS>, grid, dim3(NTH), (size_t)CS * lw * 4, (hipStream_t)stream, a, CG, TT, lw);
+        CTN_CHECK_LAUNCH("ctn_dw_fwd");
+        return CTN_OK;
+    }
     dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
     hipLaunchKernelGGL(dw_fwd_kernel, grid, dim3(NTH), (size_t)lw * 4, (hipStream_t)stream, a, CG, TT, lw);
     CTN_CHECK_LAUNCH("ctn_dw_fwd");

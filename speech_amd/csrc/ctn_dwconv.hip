@@ -468,6 +468,171 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward, cLN tiles
+// Cumulative norm on both sides: per-frame statistics, so a block walks CG channels of one time tile (TT <= 4 * NTH
+// frames) and keeps the per-frame sums of the norm-1 backward in registers.  What the general kernel above does per
+// channel and element -- guarded loads, six per-frame statistics fetched as scalars -- happens here once per block:
+// the statistics of a thread's staging columns do not depend on the channel, so they are loaded as float4s before the
+// channel loop; two channels are staged per phase, all their loads issued first from clamped addresses, validity
+// applied by selects.  LDS per channel: D | Xh as above.
+template <int P>
+__global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a, const int CG, const int TT,
+                                                         const int lw, const int H) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [CS][D | Xh][lw]
+    constexpr int CS = 2, NITB = 2;                    // host guarantees lw / 4 <= NITB * NTH
+    constexpr int NV = 5 + P;
+    __shared__ float red[CS * NV * (NTH / 64)];
+    const int b = blockIdx.z, c0 = blockIdx.y * CG, t0 = blockIdx.x * TT;
+    const int T = a.T, d = a.dilation, padL = a.pad_left;
+    const int tA = floor4(t0 - H);
+    const int tid = threadIdx.x;
+    const float a1 = a.alpha1[0], a2 = a.alpha2[0];
+    const int cend = min(c0 + CG, a.C);
+    const int t_end = min(t0 + TT, T);
+    const int lw4 = lw / 4;
+    const int tl4 = ((T + 3) & ~3) - 4;
+
+    // per-frame statistics of this thread's staging columns
+    f32x4 mu2[NITB], rs2[NITB], k1[NITB], k2[NITB], mu1[NITB], rs1[NITB];
+    int ts[NITB];
+    bool in_row[NITB];
+#pragma unroll
+    for (int j = 0; j < NITB; ++j) {
+        const int i4 = tid + j * NTH;
+        const int t = tA + 4 * i4;
+        in_row[j] = i4 < lw4 && t >= 0 && t < T;
+        ts[j] = min(max(t, 0), tl4);
+        const int64_t s2 = (int64_t)b * a.ssb2 + ts[j], s1 = (int64_t)b * a.ssb1 + ts[j];
+        mu2[j] = ctn_ld4(a.mean2 + s2); rs2[j] = ctn_ld4(a.rstd2 + s2);
+        k1[j] = ctn_ld4(a.c1_2 + s2);   k2[j] = ctn_ld4(a.c2_2 + s2);
+        mu1[j] = ctn_ld4(a.mean1 + s1); rs1[j] = ctn_ld4(a.rstd1 + s1);
+    }
+    float dalpha2 = 0.f;
+    float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
+    const int t = t0 + 4 * tid;                        // this thread's output frames (one float4 per channel)
+
+    for (int cg = c0; cg < cend; cg += CS) {
+        f32x4 vdn[CS][NITB], vx[CS][NITB], vy[CS][NITB];
+#pragma unroll
+        for (int r = 0; r < CS; ++r) {
+            const int c = min(cg + r, cend - 1);
+#pragma unroll
+            for (int j = 0; j < NITB; ++j) {
+                vdn[r][j] = CTN_DW_LD(a.dn2 + (int64_t)b * a.dn2bs + (int64_t)c * a.lddn2 + ts[j]);
+                vy[r][j] = CTN_DW_LD(a.y2 + (int64_t)b * a.y2bs + (int64_t)c * a.ldy2 + ts[j]);
+                vx[r][j] = CTN_DW_LD(a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx + ts[j]);
+            }
+        }
+        float v[CS * NV];
+#pragma unroll
+        for (int i = 0; i < CS * NV; ++i) v[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < CS; ++r) {
+            const bool ch_ok = cg + r < cend;
+            const float g2 = a.gamma2[min(cg + r, cend - 1)];
+            float* D = lds + (size_t)r * 2 * lw;
+            float* Xh = D + lw;
+            float dgamma2 = 0.f, dbeta2 = 0.f, dbias = 0.f;
+#pragma unroll
+            for (int j = 0; j < NITB; ++j) {
+                const int i4 = tid + j * NTH;
+                if (i4 >= lw4) continue;
+                const int tj = tA + 4 * i4;
+                f32x4 dv, xv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool valid = ch_ok && in_row[j] && tj + e < T;
+                    const bool interior = valid && tj + e >= t0 && tj + e < t_end;
+                    const float dn = vdn[r][j][e], y2 = vy[r][j][e];
+                    const float sl = y2 > 0.f ? 1.f : a2;
+                    const float xc = sl * y2 - mu2[j][e];
+                    const float du = g2 * dn * rs2[j][e] + k1[j][e] + xc * k2[j][e];
+                    const float dy = sl * du;
+                    dgamma2 += interior ? dn * xc * rs2[j][e] : 0.f;
+                    dbeta2 += interior ? dn : 0.f;
+                    dalpha2 += (interior && !(y2 > 0.f)) ? du * y2 : 0.f;
+                    dbias += interior ? dy : 0.f;
+                    dv[e] = valid ? dy : 0.f;
+                    const float u1 = (ctn_prelu(vx[r][j][e], a1) - mu1[j][e]) * rs1[j][e];
+                    xv[e] = valid ? u1 : 0.f;
+                }
+                ctn_st4(&D[4 * i4], dv);
+                ctn_st4(&Xh[4 * i4], xv);
+            }
+            v[r * NV + 0] = dgamma2; v[r * NV + 1] = dbeta2; v[r * NV + 2] = dbias;
+        }
+        __syncthreads();
+        // ---- input gradient, weight gradient, norm-1 reductions
+        if (t < t_end) {
+            const int i0 = t - tA;
+#pragma unroll
+            for (int r = 0; r < CS; ++r) {
+                const int c = cg + r;
+                if (c >= cend) break;
+                const float* D = lds + (size_t)r * 2 * lw;
+                const float* Xh = D + lw;
+                const float g1 = a.gamma1[c], be1 = a.beta1[c];
+                const f32x4 dy4 = ctn_ld4(&D[i0]);
+                const f32x4 xh4 = ctn_ld4(&Xh[i0]);
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const f32x4 dk = lds_read4(D, i0 - k * d + padL);
+                    const f32x4 xk = lds_read4(Xh, i0 + k * d - padL);
+                    o += a.w[(int64_t)c * P + k] * dk;
+                    float dwa = 0.f, dwb = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ti = t + e + k * d - padL;
+                        dwa += dy4[e] * xk[e];
+                        dwb += (ti >= 0 && ti < T) ? dy4[e] : 0.f;
+                    }
+                    v[r * NV + 5 + k] = g1 * dwa + be1 * dwb;
+                }
+                float dgamma1 = 0.f, dbeta1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (t + e < T) {
+                        const float g = g1 * o[e];
+                        dgamma1 += o[e] * xh4[e];
+                        dbeta1 += o[e];
+                        cs1[e] += g;
+                        cs2[e] += g * xh4[e];
+                    }
+                }
+                v[r * NV + 3] = dgamma1; v[r * NV + 4] = dbeta1;
+                CTN_DW_ST(a.dx + (int64_t)b * a.dxbs + (int64_t)c * a.lddx + t, o);
+            }
+        }
+        // ---- per-channel reductions of both channels at once (its barriers also protect the LDS rows)
+        const float tot = ctn_block_sum<CS * NV>(v, red);
+        if (tid < CS * NV) {
+            const int r = tid / NV, q = tid - r * NV, c = cg + r;
+            if (c < cend) {
+                if (q == 0 && a.dgamma2) atomicAdd(a.dgamma2 + c, tot);
+                if (q == 1 && a.dbeta2) atomicAdd(a.dbeta2 + c, tot);
+                if (q == 2 && a.dbias) atomicAdd(a.dbias + c, tot);
+                if (q == 3 && a.dgamma1) atomicAdd(a.dgamma1 + c, tot);
+                if (q == 4 && a.dbeta1) atomicAdd(a.dbeta1 + c, tot);
+                if (q >= 5) atomicAdd(a.dw + (int64_t)c * P + (q - 5), tot);
+            }
+        }
+    }
+    {
+        float v1[1] = {dalpha2};
+        const float tot = ctn_block_sum<1>(v1, red);
+        if (tid == 0 && a.dalpha2) atomicAdd(a.dalpha2 + ctn_slot(), (double)tot);
+    }
+    if (a.icol && t < t_end) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t + e < T) {
+                atomicAdd(a.icol + ((int64_t)b * 2 + 0) * a.icol_ld + t + e, cs1[e]);
+                atomicAdd(a.icol + ((int64_t)b * 2 + 1) * a.icol_ld + t + e, cs2[e]);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ backward, gLN rows
 // The separator's hot case as straight-line code: per-batch statistics (gLN), output-side norm/PReLU backward,
 // input-side PReLU + norm, one block per (batch, channel) row that fits 4 float4 per thread.  Every global load
@@ -680,6 +845,27 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
     int CG, TT, lw;
     pick_tile(a.T, 2 * H, a.cln != 0, 2, &CG, &TT, &lw);
     CTN_REQUIRE((size_t)lw * 8 <= 64 * 1024, "ctn_dw_bwd: dilation halo too large for LDS");
+    {   // cumulative norm on both sides (the causal separator's configuration), statistics rows 16-byte aligned
+        auto row_ok = [&](const float* p, int64_t sb) { return ctn_aligned16(p) && sb % 4 == 0 && sb >= ((a.T + 3) & ~3); };
+        const bool full = (a.oflags & CTN_XF_NORMBWD) && (a.xflags & CTN_XF_NORM) && (a.xflags & CTN_XF_PRELU) &&
+                          a.alpha1 && a.alpha2 && a.cln && a.sst1 == 1 && a.sst2 == 1 && a.P <= 4 && a.T >= 4 &&
+                          lw / 4 <= 2 * NTH && row_ok(a.mean1, a.ssb1) && row_ok(a.rstd1, a.ssb1) &&
+                          row_ok(a.mean2, a.ssb2) && row_ok(a.rstd2, a.ssb2) && row_ok(a.c1_2, a.ssb2) &&
+                          row_ok(a.c2_2, a.ssb2);
+        if (full) {
+            CG = 16;
+            dim3 gridc(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
+            const size_t shm = (size_t)2 * 2 * lw * 4;
+            switch (a.P) {
+                case 1: hipLaunchKernelGGL(dw_bwd_cln_kernel<1>, gridc, dim3(NTH), shm, s, a, CG, TT, lw, H); break;
+                case 2: hipLaunchKernelGGL(dw_bwd_cln_kernel<2>, gridc, dim3(NTH), shm, s, a, CG, TT, lw, H); break;
+                case 3: hipLaunchKernelGGL(dw_bwd_cln_kernel<3>, gridc, dim3(NTH), shm, s, a, CG, TT, lw, H); break;
+                default: hipLaunchKernelGGL(dw_bwd_cln_kernel<4>, gridc, dim3(NTH), shm, s, a, CG, TT, lw, H); break;
+            }
+            CTN_CHECK_LAUNCH("ctn_dw_bwd");
+            return CTN_OK;
+        }
+    }
     dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
     const size_t shmem = (size_t)lw * 8;
 #define CTN_DW_BWD_CASE(PP) \

@@ -7,6 +7,8 @@
 // norm are applied while staging (zero padding is applied AFTER the norm, as F.pad does in
 // src/models/tdcn.py:132), statistics of the output-side PReLU are reduced on the way out, so each
 // activation crosses HBM exactly once in each direction.
+#include <algorithm>
+
 #include "ctn_common.h"
 
 // Activations stream through these kernels once: non-temporal loads and stores (4 % on the forward, 2 % on the backward
@@ -168,6 +170,27 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
     }
 }
 
+// Per-frame sums of a block's time tile -> global rows col[0][t], col[1][t].  A thread holds four consecutive frames;
+// adding them from registers makes every atomic instruction of a wave touch 64 addresses 16 bytes apart (sixteen
+// 64-byte lines), and the memory side executes atomics per line.  Through LDS, consecutive lanes add consecutive
+// frames: four lines per instruction.  All threads of the block must call; LDS (>= 8 * NTH floats) is overwritten.
+__device__ __forceinline__ void col_atomics(float* lds, const float (&cs1)[4], const float (&cs2)[4], float* col,
+                                            const int64_t col_ld, const int t0, const int t_end) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    ctn_st4(&lds[4 * tid], f32x4{cs1[0], cs1[1], cs1[2], cs1[3]});
+    ctn_st4(&lds[4 * NTH + 4 * tid], f32x4{cs2[0], cs2[1], cs2[2], cs2[3]});
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * NTH;
+        if (t0 + i < t_end) {
+            atomicAdd(col + t0 + i, lds[i]);
+            atomicAdd(col + col_ld + t0 + i, lds[4 * NTH + i]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ forward, cLN
 // Cumulative norm: the statistics of the output are per-frame sums over ALL channels, so a block walks CG channels of
 // one time tile (TT <= 4 * NTH frames: one float4 of output per thread and channel) and keeps the per-frame sums in
@@ -267,14 +290,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
         }
         __syncthreads();
     }
-    if (do_stats && t < t_end) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (t + e < T) {
-                atomicAdd(a.ecol + ((int64_t)b * 2 + 0) * a.ecol_ld + t + e, cs1[e]);
-                atomicAdd(a.ecol + ((int64_t)b * 2 + 1) * a.ecol_ld + t + e, cs2[e]);
-            }
-    }
+    if (do_stats) col_atomics(lds, cs1, cs2, a.ecol + (int64_t)b * 2 * a.ecol_ld, a.ecol_ld, t0, t_end);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -623,14 +639,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
         const float tot = ctn_block_sum<1>(v1, red);
         if (tid == 0 && a.dalpha2) atomicAdd(a.dalpha2 + ctn_slot(), (double)tot);
     }
-    if (a.icol && t < t_end) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (t + e < T) {
-                atomicAdd(a.icol + ((int64_t)b * 2 + 0) * a.icol_ld + t + e, cs1[e]);
-                atomicAdd(a.icol + ((int64_t)b * 2 + 1) * a.icol_ld + t + e, cs2[e]);
-            }
-    }
+    if (a.icol) col_atomics(lds, cs1, cs2, a.icol + (int64_t)b * 2 * a.icol_ld, a.icol_ld, t0, t_end);
 }
 
 // ------------------------------------------------------------------------------------------ backward, gLN rows
@@ -796,7 +805,8 @@ int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream) {
     if (a.cln && stats && (a.P - 1) * a.dilation <= 500 && (!(a.xflags & CTN_XF_NORM) || a.sst == 1)) {
         CG = 16;
         dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
-        hipLaunchKernelGGL(dw_fwd_cln_kernel<CS>, grid, dim3(NTH), (size_t)CS * lw * 4, (hipStream_t)stream, a, CG, TT, lw);
+        const size_t shm = std::max((size_t)CS * lw, (size_t)8 * NTH) * 4;   // rows, or the per-frame sums on the way out
+        hipLaunchKernelGGL(dw_fwd_cln_kernel<CS>, grid, dim3(NTH), shm, (hipStream_t)stream, a, CG, TT, lw);
         CTN_CHECK_LAUNCH("ctn_dw_fwd");
         return CTN_OK;
     }
@@ -855,7 +865,7 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
         if (full) {
             CG = 16;
             dim3 gridc(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
-            const size_t shm = (size_t)2 * 2 * lw * 4;
+            const size_t shm = std::max((size_t)2 * 2 * lw, (size_t)8 * NTH) * 4;
             switch (a.P) {
                 case 1: hipLaunchKernelGGL(dw_bwd_cln_kernel<1>, gridc, dim3(NTH), shm, s, a, CG, TT, lw, H); break;
                 case 2: hipLaunchKernelGGL(dw_bwd_cln_kernel<2>, gridc, dim3(NTH), shm, s, a, CG, TT, lw, H); break;

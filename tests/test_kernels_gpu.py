@@ -328,7 +328,11 @@ def test_depthwise_plain(d, P, pad_left, T):
     assert_close(bg.grad, b.grad, 5e-5, "dw db")
 
 
-@pytest.mark.parametrize("L,S,T,relu", [(16, 8, 1000, False), (16, 8, 32000, True), (2, 1, 500, False), (16, 4, 403, True)])
+@pytest.mark.parametrize("L,S,T,relu", [(16, 8, 1000, False), (16, 8, 32000, True), (2, 1, 500, False), (16, 4, 403, True),
+                                        (16, 8, 16, False),       # one frame
+                                        (16, 16, 4096, True),     # no overlap between frames
+                                        (10, 5, 1005, False),     # taps and stride that are not powers of two
+                                        (3, 1, 77, True), (8, 2, 64001, False), (2, 1, 64000, False)])
 def test_encoder_decoder(L, S, T, relu):
     import convtasnet_oracle as O
     from speech_amd.functional import EncoderFn, DecoderFn

@@ -70,6 +70,30 @@ def test_resblock_golden(golden, name, dil, causal, dual):
         assert_close(p.grad, g["{}_d_{}".format(name, k)], TOL, "d" + k)
 
 
+@pytest.mark.parametrize("S,B,T", [(1, 3, 100), (2, 1, 3), (2, 5, 7), (3, 2, 4001), (4, 3, 64), (4, 1, 80000), (2, 33, 32000)])
+def test_pit_shape_sweep_vs_float64(S, B, T):
+    """PIT SI-SDR for 1..4 sources (1, 2, 6, 24 permutations), three-sample, ragged and long signals, against the
+    float64 oracle: permutations bit-exact, losses and the gradient at the strict bar."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    tgt = synth.normal((B, S, T), 201)
+    est = 0.7 * tgt[:, torch.randperm(S, generator=torch.Generator().manual_seed(S + T))] + 0.5 * synth.normal((B, S, T), 202)
+    e64 = est.double().requires_grad_(True)
+    loss64, perm64 = O.pit_neg_sisdr(e64, tgt.double())
+    loss64.backward()
+    lb64, _ = O.pit_neg_sisdr(est.double(), tgt.double(), batch_mean=False)
+    eg = est.to(dev()).requires_grad_(True)
+    crit = PIT1d(NegSISDR(), S)
+    loss, perm = crit(eg, tgt.to(dev()))
+    loss.backward()
+    lb, perm_b = crit(est.to(dev()), tgt.to(dev()), batch_mean=False)
+    torch.cuda.synchronize()
+    assert torch.equal(perm.cpu(), perm64) and torch.equal(perm_b.cpu(), perm64)
+    assert_close(loss.reshape(1), loss64.reshape(1), TOL, "loss")
+    assert_close(lb, lb64, TOL, "per-utterance loss")
+    assert_close(eg.grad, e64.grad, TOL, "dest")
+
+
 @pytest.mark.parametrize("name", ["rand2", "rand3", "tie", "swap", "silent"])
 def test_pit_golden(golden, name):
     from speech_amd.criterion.pit import PIT1d

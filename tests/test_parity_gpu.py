@@ -448,3 +448,42 @@ def test_resblock_shape_sweep_vs_float64(case, smooth):
     check(xg.grad, x64.grad, "dx")
     for k, p in mod.named_parameters():
         check(p.grad, sd64[k].grad, "d" + k)
+
+
+@pytest.mark.parametrize("variant", ["softmax_mask", "four_sources", "input_4d"])
+def test_modular_path_variants_vs_float64(variant):
+    """Configurations the fused schedule does not take and the module-by-module path serves (same kernels, one autograd
+    node per module): the softmax mask -- over all n_sources * N channels jointly, as src/models/conv_tasnet.py:346,375
+    applies it -- four sources, and the 4-D input form (B, 1, n_mics = 1, T) of conv_tasnet.py:138-141; kink-free
+    slopes, strict bar."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    cfg = dict(O.CONFIG_SMALL)
+    if variant == "softmax_mask":
+        cfg["mask_nonlinear"] = "softmax"
+    if variant == "four_sources":
+        cfg["n_sources"] = 4
+    sd = cases.e2e_state(cfg)
+    for k in sd:
+        if k.endswith("nonlinear1d.weight") or k.endswith("prelu.weight"):
+            sd[k].fill_(1.0)
+    mixture, sources = cases.e2e_batch(cfg, 2, 4001, 13)
+    loss64, perm64, out64, g64 = O.loss_and_grads(mixture.double(), sources.double(), {k: v.double() for k, v in sd.items()},
+                                                  cfg)
+    model = load_state(build(cfg), sd)
+    assert model._fused_ok() == (variant == "input_4d")
+    x = mixture.to(dev())
+    if variant == "input_4d":
+        out = model(x.unsqueeze(2))
+        assert tuple(out.shape) == (2, cfg["n_sources"], 1, 4001)
+        out = out.squeeze(2)
+    else:
+        out = model(x)
+    loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(perm.cpu(), perm64)
+    assert_close(out, out64, TOL, "out")
+    assert_close(loss.reshape(1), loss64.reshape(1), TOL, "loss")
+    for k, p in model.named_parameters():
+        assert_close(p.grad, g64[k], 3e-4 if p.numel() == 1 else TOL, "grad " + k)

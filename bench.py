@@ -129,6 +129,31 @@ def device_copy_rate(device, mbytes=1024, reps=10):
     return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def plain_gemm_rate(device, constant, batch=16, reps=30):
+    """TFLOP/s of the plain 512 x 512 pointwise GEMM at the workload's frame count on random or constant operands: the
+    f32 MFMA clock the chip sustains depends on how many operand bits toggle, so the rate on random data -- not the
+    nominal peak -- is what a kernel of this design can reach on real activations."""
+    from speech_amd import ops
+    M = K = 512
+    T = (T_SAMPLES - 16) // 8 + 1
+    A = torch.empty(K, M, device=device)
+    X = ops.new_act(batch, K, T, device)
+    if constant:
+        A.fill_(1.0); X.fill_(1.0)
+    else:
+        A.normal_(); X.normal_()
+    Y = ops.new_act(batch, M, T, device)
+    for _ in range(5):
+        ops.gemm_nn(M, T, K, batch, A, M, X, Y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm_nn(M, T, K, batch, A, M, X, Y)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * M * K * T * batch * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def cpu_baseline(cfg, steps=3, batch=2):
     """The oracle's training step (same arithmetic as the reference's loop) on the host CPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -241,7 +266,9 @@ def main():
                     traffic_source=traffic_file(args.batch),
                     mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph is the profiled command)",
                     launches_per_step=gn["launches"],
-                    avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1))
+                    avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1),
+                    plain_gemm_on_random_operands=round(plain_gemm_rate(device, False), 1),
+                    plain_gemm_on_constant_operands=round(plain_gemm_rate(device, True), 1))
         b = gt["work"] / (gt["ms"] * 1e-3) / 1e12
         extra["roofline_wgrad"] = dict(bound="mfma", kernel="gemm_nt_fast_kernel (weight gradients)", achieved=round(b, 2),
                                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",

@@ -185,6 +185,8 @@ def main():
                     help="launch every kernel eagerly instead of replaying the forward/backward pass from a HIP graph")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches of a rank's shard run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-probe", action="store_true",
+                    help="skip the second, informational measurement with split-bf16 GEMM products")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -249,6 +251,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     final_loss = float(losses[-1].item()) if losses else float("nan")
+
+    # Informational second measurement, never `value`: the same K steps with the GEMM products on the bf16 MFMA from
+    # operands split into two bf16 pieces (opt-in mode, ctn_gemm_set_split).  Every rank runs it (the steps all-reduce).
+    split_probe = None
+    if not args.no_split_probe:
+        from speech_amd import ops as _ops
+        _ops.set_gemm_split(True)
+        try:
+            trainer._graphs.clear()            # captured graphs hold the f32 kernels
+            trainer._eager_steps = 0
+            for i in range(3 + args.warmup):
+                trainer.step(*batches[i % n_batches])
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                loss_s, _ = trainer.step(*batches[i % n_batches])
+            barrier()
+            dts = time.perf_counter() - t1
+            ts = torch.tensor([dts], device="cpu" if rehearsal else device, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            split_probe = dict(value=round(args.batch * world * args.steps / ts.item(), 3), unit="utt/s",
+                               ms_per_step=round(ts.item() / args.steps * 1e3, 3), final_loss=round(float(loss_s.item()), 4),
+                               note="opt-in mode, not the headline: GEMM products as hi*hi + hi*lo + lo*hi of bf16 pieces on "
+                                    "the bf16 MFMA, fp32 accumulation; waveforms and loss stay within 1e-4 of the reference "
+                                    "(tests/test_split_gpu.py)")
+        finally:
+            _ops.set_gemm_split(False)
+            trainer._graphs.clear()
+            trainer._eager_steps = 0
 
     roof = roof_hbm = None
     extra = {}
@@ -315,6 +347,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp{}".format(world), "sub_batch_streams": args.streams,
                        "hip_graph": bool(args.graph), "final_loss": round(final_loss, 4)},
+            "split_bf16_mode": split_probe,
             "roofline": roof,
             "roofline_hbm": roof_hbm,
             "cpu_baseline": cpu,

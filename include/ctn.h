@@ -76,6 +76,14 @@ int ctn_sizeof_dw_bwd_args(void);
  * Process-wide; returns CTN_ERR_ARG for any other value. */
 int ctn_gemm_nn_set_tile(int width);
 
+/* Opt-in arithmetic mode without a counterpart in the reference: the products of ctn_gemm_nn run on the bf16 MFMA from
+ * operands split into two bf16 pieces each (x = hi + lo, 17 mantissa bits), three instructions per tile -- hi*hi + hi*lo
+ * + lo*hi -- with fp32 accumulation, instead of f32 MFMAs.  About twice the rate; each GEMM then agrees with fp32
+ * arithmetic to about 1e-5 of its largest output instead of 1e-6.  Off by default (also switched on by CTN_GEMM_SPLIT=1 in
+ * the environment at first use).  Process-wide. */
+int ctn_gemm_set_split(int on);
+int ctn_gemm_get_split(void);
+
 /* dst[k * ldd + coff + m] = src[m * K + k]  (m < M, k < K).  Lays a Conv1d(kernel_size=1) weight
  * (M_out, K_in) out k-major for ctn_gemm_nn. */
 int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64_t coff, void* stream);

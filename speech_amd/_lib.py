@@ -113,6 +113,8 @@ PROTOTYPES = {
     "ctn_version": (C.c_char_p, []),
     "ctn_last_error": (C.c_char_p, []),
     "ctn_gemm_nn_set_tile": (C.c_int, [C.c_int]),
+    "ctn_gemm_set_split": (C.c_int, [C.c_int]),
+    "ctn_gemm_get_split": (C.c_int, []),
     "ctn_sizeof_gemm_nn_args": (C.c_int, []),
     "ctn_sizeof_gemm_nt_args": (C.c_int, []),
     "ctn_sizeof_dw_fwd_args": (C.c_int, []),

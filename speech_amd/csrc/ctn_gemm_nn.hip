@@ -415,8 +415,29 @@ extern "C" int ctn_debug_read_stamps(unsigned long long* dst) {
 
 // 4 blocks (waves per SIMD) per CU for both widths: 128 unified registers per lane, so that a launch of
 // 1024 x k blocks runs in whole generations.
-template <int FBN_, int XF, bool BWD>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Eight floats -> their two leading bf16 pieces, both rounded to nearest: hi = bf16(x), lo = bf16(x - hi) (the
+// remainder is exact in fp32).  hi + lo carries 17 mantissa bits of x.  Per pair of floats: two packed conversions,
+// two unpacking operations and two subtractions.
+__device__ __forceinline__ void ctn_split_bf16(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+    union { bf16x8 v; bf16x2 p[4]; unsigned u[4]; } h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h.p[i] = __builtin_convertvector(f32x2{x[2 * i], x[2 * i + 1]}, bf16x2);
+        const float h0 = __uint_as_float(h.u[i] << 16), h1 = __uint_as_float(h.u[i] & 0xffff0000u);
+        l.p[i] = __builtin_convertvector(f32x2{x[2 * i] - h0, x[2 * i + 1] - h1}, bf16x2);
+    }
+    hi = h.v, lo = l.v;
+}
+
+// SPLIT: the products run on the bf16 MFMA (16 k per instruction, 8 passes) from split operands, three instructions
+// per tile and k-tile -- hi*hi + hi*lo + lo*hi, fp32 accumulation -- instead of eight f32 MFMAs of 16 passes each.
+template <int FBN_, int XF, bool BWD, bool SPLIT = false>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT ? 3 : 4, 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
     // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -591,6 +612,43 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float* Xs = As + TILE_A;
         const float* X2s = Xs + TILE_X;
         const int k0 = kt * FBK;
+        if constexpr (SPLIT) {
+            static_assert(FBK == 16, "split variant: one bf16 MFMA per 16-row k-tile");
+            // lane half h owns rows 8h .. 8h+7 of the k-tile; one fragment is live in fp32 at a time
+            bf16x8 bh[NJ], bl[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float bf[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = 8 * half + q;
+                    float v = Xs[k * FBN_ + wn0 + j * 32 + l31];
+                    if (BWD) {
+                        const float y = X2s[k * FBN_ + wn0 + j * 32 + l31];
+                        const float sl = y > 0.f ? 1.f : alpha;
+                        v = sl * __builtin_fmaf(Gs[k0 + k] * v, rstd[j], __builtin_fmaf(sl * y, c2[j], c1m[j]));
+                    }
+                    if (XF & CTN_XF_PRELU) v = ctn_prelu_med(v, alpha, plim);
+                    if (XF & CTN_XF_NORM) v = __builtin_fmaf(__builtin_fmaf(v, rstd[j], nmr[j]), Gs[k0 + k], Bes[k0 + k]);
+                    bf[q] = v;
+                }
+                ctn_split_bf16(bf, bh[j], bl[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float af[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) af[q] = As[(8 * half + q) * FBM + wm0 + i * 32 + l31];
+                bf16x8 ah, al;
+                ctn_split_bf16(af, ah, al);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < FBK / 2; ++kk) {
             const int k = 2 * kk + half;
@@ -865,6 +923,16 @@ int pick_fbn(const ctn_gemm_nn_args& a) {
     return fill(128) >= fill(64) - 0.02 ? 128 : 64;
 }
 
+// Split-bf16 products (see gemm_nn_fast_kernel): off unless ctn_gemm_set_split(1) was called or CTN_GEMM_SPLIT=1 is set.
+int g_split = -1;
+bool gemm_split() {
+    if (g_split < 0) {
+        const char* e = getenv("CTN_GEMM_SPLIT");
+        g_split = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return g_split != 0;
+}
+
 template <int FBN_>
 int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
     const int tiles_m = ctn_cdiv(a.M, FBM), tiles_n = ctn_cdiv(a.T, FBN_);
@@ -876,8 +944,31 @@ int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
     const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
     const size_t shmem = fast_lds_bytes(a, FBN_);
     const dim3 grid((unsigned)total), block(NTH);
+    const bool split = gemm_split();
     if (bwd) {
-        hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
+        if (split)
+            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
+        return CTN_OK;
+    }
+    if (split) {
+        switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {
+            case 0:
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, false, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
+                break;
+            case CTN_XF_PRELU:
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU, false, true>), grid, block, shmem, s, a,
+                                   tiles_m, tiles_n);
+                break;
+            case CTN_XF_NORM:
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_NORM, false, true>), grid, block, shmem, s, a,
+                                   tiles_m, tiles_n);
+                break;
+            default:
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU | CTN_XF_NORM, false, true>), grid, block, shmem,
+                                   s, a, tiles_m, tiles_n);
+        }
         return CTN_OK;
     }
     switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {
@@ -921,6 +1012,13 @@ int launch(const ctn_gemm_nn_args& a, int vecA, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int ctn_gemm_set_split(int on) {
+    g_split = on ? 1 : 0;
+    return CTN_OK;
+}
+
+extern "C" int ctn_gemm_get_split(void) { return gemm_split() ? 1 : 0; }
 
 extern "C" int ctn_gemm_nn_set_tile(int width) {
     CTN_REQUIRE(width == 0 || width == 64 || width == 128, "ctn_gemm_nn_set_tile: width must be 0, 64 or 128");

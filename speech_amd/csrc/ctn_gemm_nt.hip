@@ -250,7 +250,25 @@ void launch(const ctn_gemm_nt_args& a, hipStream_t s) {
 
 // CLN: the statistics are rows over frames (cumulative norm) instead of one value per batch element; every use
 // fetches the four frames of its group with one 16-byte load from a row that stays in L2.
-template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN>
+typedef __bf16 ntbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ntbf16x2 __attribute__((ext_vector_type(2)));
+typedef float ntf32x2 __attribute__((ext_vector_type(2)));
+
+// Eight floats -> two bf16 pieces each, hi = bf16(x), lo = bf16(x - hi), both rounded to nearest.
+__device__ __forceinline__ void nt_split_bf16(const float (&x)[8], ntbf16x8& hi, ntbf16x8& lo) {
+    union { ntbf16x8 v; ntbf16x2 p[4]; unsigned u[4]; } h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h.p[i] = __builtin_convertvector(ntf32x2{x[2 * i], x[2 * i + 1]}, ntbf16x2);
+        const float h0 = __uint_as_float(h.u[i] << 16), h1 = __uint_as_float(h.u[i] & 0xffff0000u);
+        l.p[i] = __builtin_convertvector(ntf32x2{x[2 * i] - h0, x[2 * i + 1] - h1}, ntbf16x2);
+    }
+    hi = h.v, lo = l.v;
+}
+
+// SPLIT: products on the bf16 MFMA from operands split into two bf16 pieces (hi*hi + hi*lo + lo*hi, fp32
+// accumulation), one instruction triple per 16 frames instead of eight f32 MFMAs; see ctn_gemm_set_split.
+template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN, bool SPLIT = false>
 __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
                                                            const int tiles_n, const int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -411,6 +429,55 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     auto compute = [&](const float* As, int t0, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const float* Bs = As + FTA;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int c2 = 0; c2 < FK / 16; ++c2) {        // 16 frames per bf16 MFMA: this half-wave's two frame groups
+                float a8[TTM][8], b8[TTN][8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = 2 * c2 + u;
+                    const int grp = 2 * c + half;
+                    const int so = ((grp ^ fsw) * 4);
+                    const int tf = t0 + 4 * grp;
+#pragma unroll
+                    for (int i = 0; i < TTM; ++i) {
+                        const f32x4 v = ctn_ld4(&As[arow_off + i * 32 * FK + so]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a8[i][4 * u + e] = (!BWD && TAIL && !(tf + e < t_end)) ? 0.f : v[e];
+                        if (!BWD && do_rowsum)
+                            rowsum[i] += (a8[i][4 * u] + a8[i][4 * u + 1]) + (a8[i][4 * u + 2] + a8[i][4 * u + 3]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TTN; ++j) {
+                        f32x4 v = ctn_ld4(&Bs[brow_off + j * 32 * FK + so]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float w = v[e];
+                            if (BXF & CTN_XF_PRELU) w = ctn_prelu_med(w, b_alpha, bplim);
+                            if (BXF & CTN_XF_NORM)
+                                w = BSTAT ? (w - bmv[c][e]) * brv[c][e] * bg[j] + bb[j] : __builtin_fmaf(w, bg[j], bb[j]);
+                            if (TAIL && !(tf + e < t_end)) w = 0.f;
+                            b8[j][4 * u + e] = w;
+                        }
+                    }
+                }
+                ntbf16x8 bh[TTN], bl[TTN];
+#pragma unroll
+                for (int j = 0; j < TTN; ++j) nt_split_bf16(b8[j], bh[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < TTM; ++i) {
+                    ntbf16x8 ah, al;
+                    nt_split_bf16(a8[i], ah, al);
+#pragma unroll
+                    for (int j = 0; j < TTN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < FK / 8; ++c) {
             const int grp = 2 * c + half;                 // logical frame group of this half-wave
@@ -672,12 +739,22 @@ void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
     const size_t tile_floats = (size_t)(TM + TN + (BWD ? TM : 0)) * FK;
     const size_t shmem = (BWD ? 3 : 2) * tile_floats * sizeof(float);
-    if (stat_rows(a))
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true>), dim3(total), dim3(NTH), shmem, s, a,
-                           tiles_m, tiles_n, nchunks);
-    else
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false>), dim3(total), dim3(NTH), shmem, s, a,
-                           tiles_m, tiles_n, nchunks);
+    const bool split = ctn_gemm_get_split() != 0;
+    if (stat_rows(a)) {
+        if (split)
+            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true, true>), dim3(total), dim3(NTH), shmem, s, a,
+                               tiles_m, tiles_n, nchunks);
+        else
+            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true>), dim3(total), dim3(NTH), shmem, s, a,
+                               tiles_m, tiles_n, nchunks);
+    } else {
+        if (split)
+            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false, true>), dim3(total), dim3(NTH), shmem, s, a,
+                               tiles_m, tiles_n, nchunks);
+        else
+            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false>), dim3(total), dim3(NTH), shmem, s, a,
+                               tiles_m, tiles_n, nchunks);
+    }
 }
 
 void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) {

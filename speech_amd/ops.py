@@ -146,6 +146,18 @@ class Accum:
             self.sums = zeros((B, _lib.STAT_SLOTS, 2), device, torch.float64)
 
 
+# ------------------------------------------------------------------------------------------------ arithmetic mode
+def set_gemm_split(on):
+    """Process-wide: run the products of the pointwise and weight-gradient GEMMs on the bf16 MFMA from operands split
+    into two bf16 pieces (three products, fp32 accumulation) instead of f32 MFMAs; see ctn_gemm_set_split in
+    include/ctn.h.  Off by default.  HIP graphs captured before the switch keep the kernels they captured."""
+    _lib.check(_lib.load().ctn_gemm_set_split(1 if on else 0), "ctn_gemm_set_split")
+
+
+def get_gemm_split():
+    return bool(_lib.load().ctn_gemm_get_split())
+
+
 # ------------------------------------------------------------------------------------------------ chunking
 def segment(x, K, P, S, pad_left=0):
     """(B, C, T) -> dense (B, C, S, K): chunk s holds frames s*P .. s*P+K-1 of x zero-padded by pad_left in front."""

@@ -252,33 +252,40 @@ def main():
     dt = t.item()
     final_loss = float(losses[-1].item()) if losses else float("nan")
 
-    # Informational second measurement, never `value`: the same K steps with the GEMM products on the bf16 MFMA from
-    # operands split into two bf16 pieces (opt-in mode, ctn_gemm_set_split).  Every rank runs it (the steps all-reduce).
+    # Informational extra measurements, never `value`: the same K steps with the GEMM products on the bf16 MFMA from
+    # operands split into bf16 pieces (opt-in modes, ctn_gemm_set_split).  Every rank runs them (the steps all-reduce).
     split_probe = None
     if not args.no_split_probe:
         from speech_amd import ops as _ops
-        _ops.set_gemm_split(True)
+        notes = {2: "opt-in mode, not the headline: GEMM products as hi*hi + hi*lo + lo*hi of two bf16 pieces per operand "
+                    "on the bf16 MFMA, fp32 accumulation; waveforms and loss stay within 1e-4 of the reference "
+                    "(tests/test_split_gpu.py)",
+                 3: "opt-in mode, not the headline: three bf16 pieces per operand (an exact representation of the fp32 "
+                    "value) and the six leading products on the bf16 MFMA, fp32 accumulation; meets the f32-MFMA mode's "
+                    "GEMM bounds (tests/test_split_gpu.py)"}
+        split_probe = {}
         try:
-            trainer._graphs.clear()            # captured graphs hold the f32 kernels
-            trainer._eager_steps = 0
-            for i in range(3 + args.warmup):
-                trainer.step(*batches[i % n_batches])
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                loss_s, _ = trainer.step(*batches[i % n_batches])
-            barrier()
-            dts = time.perf_counter() - t1
-            ts = torch.tensor([dts], device="cpu" if rehearsal else device, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-            split_probe = dict(value=round(args.batch * world * args.steps / ts.item(), 3), unit="utt/s",
-                               ms_per_step=round(ts.item() / args.steps * 1e3, 3), final_loss=round(float(loss_s.item()), 4),
-                               note="opt-in mode, not the headline: GEMM products as hi*hi + hi*lo + lo*hi of bf16 pieces on "
-                                    "the bf16 MFMA, fp32 accumulation; waveforms and loss stay within 1e-4 of the reference "
-                                    "(tests/test_split_gpu.py)")
+            for pieces in (2, 3):
+                _ops.set_gemm_split(pieces)
+                trainer._graphs.clear()            # captured graphs hold the kernels of the mode they were captured in
+                trainer._eager_steps = 0
+                for i in range(3 + args.warmup):
+                    trainer.step(*batches[i % n_batches])
+                barrier()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    loss_s, _ = trainer.step(*batches[i % n_batches])
+                barrier()
+                dts = time.perf_counter() - t1
+                ts = torch.tensor([dts], device="cpu" if rehearsal else device, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                split_probe["pieces_%d" % pieces] = dict(
+                    value=round(args.batch * world * args.steps / ts.item(), 3), unit="utt/s",
+                    ms_per_step=round(ts.item() / args.steps * 1e3, 3), final_loss=round(float(loss_s.item()), 4),
+                    note=notes[pieces])
         finally:
-            _ops.set_gemm_split(False)
+            _ops.set_gemm_split(0)
             trainer._graphs.clear()
             trainer._eager_steps = 0
 

@@ -76,12 +76,16 @@ int ctn_sizeof_dw_bwd_args(void);
  * Process-wide; returns CTN_ERR_ARG for any other value. */
 int ctn_gemm_nn_set_tile(int width);
 
-/* Opt-in arithmetic mode without a counterpart in the reference: the products of ctn_gemm_nn run on the bf16 MFMA from
- * operands split into two bf16 pieces each (x = hi + lo, 17 mantissa bits), three instructions per tile -- hi*hi + hi*lo
- * + lo*hi -- with fp32 accumulation, instead of f32 MFMAs.  About twice the rate; each GEMM then agrees with fp32
- * arithmetic to about 1e-5 of its largest output instead of 1e-6.  Off by default (also switched on by CTN_GEMM_SPLIT=1 in
- * the environment at first use).  Process-wide. */
-int ctn_gemm_set_split(int on);
+/* Opt-in arithmetic modes without a counterpart in the reference: the products of ctn_gemm_nn and ctn_gemm_nt run on the
+ * bf16 MFMA from operands split into bf16 pieces, with fp32 accumulation, instead of on f32 MFMAs.
+ *   pieces = 2 (or 1): x = hi + lo (17 mantissa bits, pieces rounded to nearest), three instructions per tile -- hi*hi +
+ *     hi*lo + lo*hi.  Each GEMM then agrees with fp32 arithmetic to about 1e-5 of its largest output instead of 1e-6.
+ *   pieces = 3: x = hi + mid + lo exactly (each piece the next eight significant bits), six instructions per tile -- every
+ *     product except mid*lo, lo*mid and lo*lo, which are below 2^-21 of the largest.  Meets the f32-MFMA bounds.
+ *   pieces = 0: f32 MFMAs, the default.
+ * CTN_GEMM_SPLIT=<pieces> in the environment selects the mode at first use.  Process-wide; returns CTN_ERR_ARG for any
+ * other value. */
+int ctn_gemm_set_split(int pieces);
 int ctn_gemm_get_split(void);
 
 /* dst[k * ldd + coff + m] = src[m * K + k]  (m < M, k < K).  Lays a Conv1d(kernel_size=1) weight

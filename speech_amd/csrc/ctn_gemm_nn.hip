@@ -434,10 +434,27 @@ __device__ __forceinline__ void ctn_split_bf16(const float (&x)[8], bf16x8& hi, 
     hi = h.v, lo = l.v;
 }
 
-// SPLIT: the products run on the bf16 MFMA (16 k per instruction, 8 passes) from split operands, three instructions
-// per tile and k-tile -- hi*hi + hi*lo + lo*hi, fp32 accumulation -- instead of eight f32 MFMAs of 16 passes each.
-template <int FBN_, int XF, bool BWD, bool SPLIT = false>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT ? 3 : 4, 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
+// Three pieces by truncation, hi + mid + lo = x exactly: each piece takes the next eight significant bits of the 24.
+__device__ __forceinline__ void ctn_split_bf16_3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    union { bf16x8 v; unsigned u[4]; } h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned x0 = __float_as_uint(x[2 * i]), x1 = __float_as_uint(x[2 * i + 1]);
+        h.u[i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        const float r0 = x[2 * i] - __uint_as_float(x0 & 0xffff0000u), r1 = x[2 * i + 1] - __uint_as_float(x1 & 0xffff0000u);
+        const unsigned ru0 = __float_as_uint(r0), ru1 = __float_as_uint(r1);
+        m.u[i] = __builtin_amdgcn_perm(ru1, ru0, 0x07060302u);
+        const float q0 = r0 - __uint_as_float(ru0 & 0xffff0000u), q1 = r1 - __uint_as_float(ru1 & 0xffff0000u);
+        l.u[i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    }
+    hi = h.v, mid = m.v, lo = l.v;
+}
+
+// SPLIT = 2: the products run on the bf16 MFMA (16 k per instruction, 8 passes) from operands split into two bf16
+// pieces, three instructions per tile and k-tile -- hi*hi + hi*lo + lo*hi, fp32 accumulation -- instead of eight f32
+// MFMAs of 16 passes each.  SPLIT = 3: three pieces and the six leading products, which keeps all 24 mantissa bits.
+template <int FBN_, int XF, bool BWD, int SPLIT = 0>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : 2), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
     // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -612,10 +629,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT ? 3 :
         const float* Xs = As + TILE_A;
         const float* X2s = Xs + TILE_X;
         const int k0 = kt * FBK;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT != 0) {
             static_assert(FBK == 16, "split variant: one bf16 MFMA per 16-row k-tile");
             // lane half h owns rows 8h .. 8h+7 of the k-tile; one fragment is live in fp32 at a time
-            bf16x8 bh[NJ], bl[NJ];
+            bf16x8 bh[NJ], bm[NJ], bl[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float bf[8];
@@ -632,21 +649,30 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT ? 3 :
                     if (XF & CTN_XF_NORM) v = __builtin_fmaf(__builtin_fmaf(v, rstd[j], nmr[j]), Gs[k0 + k], Bes[k0 + k]);
                     bf[q] = v;
                 }
-                ctn_split_bf16(bf, bh[j], bl[j]);
+                if (SPLIT == 3) ctn_split_bf16_3(bf, bh[j], bm[j], bl[j]);
+                else ctn_split_bf16(bf, bh[j], bl[j]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float af[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) af[q] = As[(8 * half + q) * FBM + wm0 + i * 32 + l31];
-                bf16x8 ah, al;
-                ctn_split_bf16(af, ah, al);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                bf16x8 ah, am, al;
+                if (SPLIT == 3) ctn_split_bf16_3(af, ah, am, al);
+                else ctn_split_bf16(af, ah, al);
+                // smallest products first; the tiles alternate so that consecutive instructions are independent
+#define CTN_NN_MFMA(a_, b_)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_[j], acc[i][j], 0, 0, 0)
+                CTN_NN_MFMA(al, bh);
+                CTN_NN_MFMA(ah, bl);
+                if (SPLIT == 3) {
+                    CTN_NN_MFMA(am, bm);
+                    CTN_NN_MFMA(am, bh);
+                    CTN_NN_MFMA(ah, bm);
                 }
+                CTN_NN_MFMA(ah, bh);
+#undef CTN_NN_MFMA
             }
         } else
 #pragma unroll
@@ -925,12 +951,13 @@ int pick_fbn(const ctn_gemm_nn_args& a) {
 
 // Split-bf16 products (see gemm_nn_fast_kernel): off unless ctn_gemm_set_split(1) was called or CTN_GEMM_SPLIT=1 is set.
 int g_split = -1;
-bool gemm_split() {
+int gemm_split() {
     if (g_split < 0) {
         const char* e = getenv("CTN_GEMM_SPLIT");
-        g_split = (e && atoi(e) != 0) ? 1 : 0;
+        const int v = e ? atoi(e) : 0;
+        g_split = (v == 1 || v == 2) ? 2 : (v == 3 ? 3 : 0);
     }
-    return g_split != 0;
+    return g_split;
 }
 
 template <int FBN_>
@@ -944,31 +971,37 @@ int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
     const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
     const size_t shmem = fast_lds_bytes(a, FBN_);
     const dim3 grid((unsigned)total), block(NTH);
-    const bool split = gemm_split();
+    const int split = gemm_split();
+#define CTN_NN_SPLIT_CASES(SP)                                                                                          \
+    do {                                                                                                                \
+        if (bwd) {                                                                                                      \
+            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true, SP>), grid, block, shmem, s, a, tiles_m, tiles_n);   \
+            return CTN_OK;                                                                                              \
+        }                                                                                                               \
+        switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {                                                              \
+            case 0:                                                                                                     \
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, false, SP>), grid, block, shmem, s, a, tiles_m,        \
+                                   tiles_n);                                                                            \
+                break;                                                                                                  \
+            case CTN_XF_PRELU:                                                                                          \
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU, false, SP>), grid, block, shmem, s, a,      \
+                                   tiles_m, tiles_n);                                                                   \
+                break;                                                                                                  \
+            case CTN_XF_NORM:                                                                                           \
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_NORM, false, SP>), grid, block, shmem, s, a,       \
+                                   tiles_m, tiles_n);                                                                   \
+                break;                                                                                                  \
+            default:                                                                                                    \
+                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU | CTN_XF_NORM, false, SP>), grid, block,     \
+                                   shmem, s, a, tiles_m, tiles_n);                                                      \
+        }                                                                                                               \
+        return CTN_OK;                                                                                                  \
+    } while (0)
+    if (split == 2) CTN_NN_SPLIT_CASES(2);
+    if (split == 3) CTN_NN_SPLIT_CASES(3);
+#undef CTN_NN_SPLIT_CASES
     if (bwd) {
-        if (split)
-            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
-        else
-            hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
-        return CTN_OK;
-    }
-    if (split) {
-        switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {
-            case 0:
-                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, false, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
-                break;
-            case CTN_XF_PRELU:
-                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU, false, true>), grid, block, shmem, s, a,
-                                   tiles_m, tiles_n);
-                break;
-            case CTN_XF_NORM:
-                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_NORM, false, true>), grid, block, shmem, s, a,
-                                   tiles_m, tiles_n);
-                break;
-            default:
-                hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, CTN_XF_PRELU | CTN_XF_NORM, false, true>), grid, block, shmem,
-                                   s, a, tiles_m, tiles_n);
-        }
+        hipLaunchKernelGGL((gemm_nn_fast_kernel<FBN_, 0, true>), grid, block, shmem, s, a, tiles_m, tiles_n);
         return CTN_OK;
     }
     switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {
@@ -1013,12 +1046,13 @@ int launch(const ctn_gemm_nn_args& a, int vecA, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int ctn_gemm_set_split(int on) {
-    g_split = on ? 1 : 0;
+extern "C" int ctn_gemm_set_split(int pieces) {
+    CTN_REQUIRE(pieces == 0 || pieces == 1 || pieces == 2 || pieces == 3, "ctn_gemm_set_split: 0 (off), 2 or 3 pieces (1 = 2)");
+    g_split = pieces == 1 ? 2 : pieces;
     return CTN_OK;
 }
 
-extern "C" int ctn_gemm_get_split(void) { return gemm_split() ? 1 : 0; }
+extern "C" int ctn_gemm_get_split(void) { return gemm_split(); }
 
 extern "C" int ctn_gemm_nn_set_tile(int width) {
     CTN_REQUIRE(width == 0 || width == 64 || width == 128, "ctn_gemm_nn_set_tile: width must be 0, 64 or 128");

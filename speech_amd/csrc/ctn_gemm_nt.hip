@@ -266,9 +266,26 @@ __device__ __forceinline__ void nt_split_bf16(const float (&x)[8], ntbf16x8& hi,
     hi = h.v, lo = l.v;
 }
 
-// SPLIT: products on the bf16 MFMA from operands split into two bf16 pieces (hi*hi + hi*lo + lo*hi, fp32
-// accumulation), one instruction triple per 16 frames instead of eight f32 MFMAs; see ctn_gemm_set_split.
-template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN, bool SPLIT = false>
+// Three pieces by truncation, hi + mid + lo = x exactly: each piece takes the next eight significant bits of the 24.
+__device__ __forceinline__ void nt_split_bf16_3(const float (&x)[8], ntbf16x8& hi, ntbf16x8& mid, ntbf16x8& lo) {
+    union { ntbf16x8 v; unsigned u[4]; } h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned x0 = __float_as_uint(x[2 * i]), x1 = __float_as_uint(x[2 * i + 1]);
+        h.u[i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        const float r0 = x[2 * i] - __uint_as_float(x0 & 0xffff0000u), r1 = x[2 * i + 1] - __uint_as_float(x1 & 0xffff0000u);
+        const unsigned ru0 = __float_as_uint(r0), ru1 = __float_as_uint(r1);
+        m.u[i] = __builtin_amdgcn_perm(ru1, ru0, 0x07060302u);
+        const float q0 = r0 - __uint_as_float(ru0 & 0xffff0000u), q1 = r1 - __uint_as_float(ru1 & 0xffff0000u);
+        l.u[i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    }
+    hi = h.v, mid = m.v, lo = l.v;
+}
+
+// SPLIT = 2: products on the bf16 MFMA from operands split into two bf16 pieces (hi*hi + hi*lo + lo*hi, fp32
+// accumulation), one instruction triple per 16 frames instead of eight f32 MFMAs; SPLIT = 3: three pieces and the six
+// leading products (all 24 mantissa bits).  See ctn_gemm_set_split.
+template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN, int SPLIT = 0>
 __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
                                                            const int tiles_n, const int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     auto compute = [&](const float* As, int t0, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const float* Bs = As + FTA;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT != 0) {
 #pragma unroll
             for (int c2 = 0; c2 < FK / 16; ++c2) {        // 16 frames per bf16 MFMA: this half-wave's two frame groups
                 float a8[TTM][8], b8[TTN][8];
@@ -461,19 +478,30 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
                         }
                     }
                 }
-                ntbf16x8 bh[TTN], bl[TTN];
+                ntbf16x8 bh[TTN], bm[TTN], bl[TTN];
 #pragma unroll
-                for (int j = 0; j < TTN; ++j) nt_split_bf16(b8[j], bh[j], bl[j]);
+                for (int j = 0; j < TTN; ++j) {
+                    if (SPLIT == 3) nt_split_bf16_3(b8[j], bh[j], bm[j], bl[j]);
+                    else nt_split_bf16(b8[j], bh[j], bl[j]);
+                }
 #pragma unroll
                 for (int i = 0; i < TTM; ++i) {
-                    ntbf16x8 ah, al;
-                    nt_split_bf16(a8[i], ah, al);
-#pragma unroll
-                    for (int j = 0; j < TTN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    ntbf16x8 ah, am, al;
+                    if (SPLIT == 3) nt_split_bf16_3(a8[i], ah, am, al);
+                    else nt_split_bf16(a8[i], ah, al);
+                    // smallest products first; the tiles alternate so that consecutive instructions are independent
+#define CTN_NT_MFMA(a_, b_)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < TTN; ++j)                                                                     \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_[j], acc[i][j], 0, 0, 0)
+                    CTN_NT_MFMA(al, bh);
+                    CTN_NT_MFMA(ah, bl);
+                    if (SPLIT == 3) {
+                        CTN_NT_MFMA(am, bm);
+                        CTN_NT_MFMA(am, bh);
+                        CTN_NT_MFMA(ah, bm);
                     }
+                    CTN_NT_MFMA(ah, bh);
+#undef CTN_NT_MFMA
                 }
             }
             return;
@@ -739,22 +767,21 @@ void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
     const size_t tile_floats = (size_t)(TM + TN + (BWD ? TM : 0)) * FK;
     const size_t shmem = (BWD ? 3 : 2) * tile_floats * sizeof(float);
-    const bool split = ctn_gemm_get_split() != 0;
-    if (stat_rows(a)) {
-        if (split)
-            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true, true>), dim3(total), dim3(NTH), shmem, s, a,
-                               tiles_m, tiles_n, nchunks);
-        else
-            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, true>), dim3(total), dim3(NTH), shmem, s, a,
-                               tiles_m, tiles_n, nchunks);
+    const int split = ctn_gemm_get_split();
+    const bool rows = stat_rows(a);
+#define CTN_NT_LAUNCH(CLN_, SP)                                                                                        \
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, CLN_, SP>), dim3(total), dim3(NTH), shmem, s, a,     \
+                       tiles_m, tiles_n, nchunks)
+    if (rows) {
+        if (split == 3) CTN_NT_LAUNCH(true, 3);
+        else if (split == 2) CTN_NT_LAUNCH(true, 2);
+        else CTN_NT_LAUNCH(true, 0);
     } else {
-        if (split)
-            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false, true>), dim3(total), dim3(NTH), shmem, s, a,
-                               tiles_m, tiles_n, nchunks);
-        else
-            hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, false>), dim3(total), dim3(NTH), shmem, s, a,
-                               tiles_m, tiles_n, nchunks);
+        if (split == 3) CTN_NT_LAUNCH(false, 3);
+        else if (split == 2) CTN_NT_LAUNCH(false, 2);
+        else CTN_NT_LAUNCH(false, 0);
     }
+#undef CTN_NT_LAUNCH
 }
 
 void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) {

@@ -147,15 +147,18 @@ class Accum:
 
 
 # ------------------------------------------------------------------------------------------------ arithmetic mode
-def set_gemm_split(on):
+def set_gemm_split(pieces):
     """Process-wide: run the products of the pointwise and weight-gradient GEMMs on the bf16 MFMA from operands split
-    into two bf16 pieces (three products, fp32 accumulation) instead of f32 MFMAs; see ctn_gemm_set_split in
-    include/ctn.h.  Off by default.  HIP graphs captured before the switch keep the kernels they captured."""
-    _lib.check(_lib.load().ctn_gemm_set_split(1 if on else 0), "ctn_gemm_set_split")
+    into bf16 pieces, with fp32 accumulation, instead of f32 MFMAs; see ctn_gemm_set_split in include/ctn.h.
+    pieces: 0 / False = off (the default), 2 / True = two pieces and three products, 3 = three pieces and six products
+    (all 24 mantissa bits).  HIP graphs captured before the switch keep the kernels they captured."""
+    level = 2 if pieces is True else int(pieces)
+    _lib.check(_lib.load().ctn_gemm_set_split(level), "ctn_gemm_set_split")
 
 
 def get_gemm_split():
-    return bool(_lib.load().ctn_gemm_get_split())
+    """0 (off), 2 or 3: the number of bf16 pieces per operand the GEMMs currently use."""
+    return int(_lib.load().ctn_gemm_get_split())
 
 
 # ------------------------------------------------------------------------------------------------ chunking

@@ -253,9 +253,10 @@ def main():
     final_loss = float(losses[-1].item()) if losses else float("nan")
 
     # Informational extra measurements, never `value`: the same K steps with the GEMM products on the bf16 MFMA from
-    # operands split into bf16 pieces (opt-in modes, ctn_gemm_set_split).  Every rank runs them (the steps all-reduce).
+    # operands split into bf16 pieces (opt-in modes, ctn_gemm_set_split).  One-GPU runs only: the multi-GPU runs measure
+    # scaling of the headline mode and nothing else.
     split_probe = None
-    if not args.no_split_probe:
+    if world == 1 and not args.no_split_probe:
         from speech_amd import ops as _ops
         notes = {2: "opt-in mode, not the headline: GEMM products as hi*hi + hi*lo + lo*hi of two bf16 pieces per operand "
                     "on the bf16 MFMA, fp32 accumulation; waveforms and loss stay within 1e-4 of the reference "

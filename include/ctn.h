@@ -330,6 +330,18 @@ int ctn_pit_sisdr_bwd(const float* est, const float* tgt, int batch, int S, int 
                       const int64_t* perm, const float* coef, const float* gscale, int gs_bstride, int gs_istride,
                       float* dest, int64_t dss, int64_t dbs, void* stream);
 
+/* The whole S x S matrix with its derivative, for the plain SDR (src/criterion/sdr.py:6-22, :24-114), for permutation
+ * searches over it and for Sinkhorn PIT (src/criterion/pit.py:163-193), which weights every pair.
+ * kind 0: pair[b][i][j] = SI-SDR(est_i, tgt_j); kind 1: pair[b][i][j] = 10 log10((|tgt_j|^2 + eps) / (|tgt_j - est_i|^2
+ * + eps)).  paircoef[b][i][j][2] = (ct, ce) with d pair[b][i][j] / d est_i = ct*tgt_j + ce*est_i.
+ * work: double[batch * (2*S*S + S)] zeroed by the caller.  S <= 4. */
+int ctn_pair_sdr_fwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs, float eps,
+                     int kind, double* work, float* pair, float* paircoef, void* stream);
+/* dest[b][i][t] = sum_j A[b][i][j]*tgt[b][j][t] + C[b][i]*est[b][i][t]   (A = upstream gradient x ct, C = sum_j of
+ * upstream gradient x ce) */
+int ctn_pair_sdr_bwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
+                     const float* A, const float* C, float* dest, int64_t dss, int64_t dbs, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Optimizer step on flat fp32 buffers (egs/wsj0-mix/common/src/driver.py:152-155:
  * clip_grad_norm_(max_norm) then torch.optim.Adam.step)

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(NTH) void pit_pass1_kernel(const float* __restrict_
 
 template <int S>
 __global__ __launch_bounds__(NTH) void pit_pass2_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
-                                                        int T, int64_t ss, int64_t bs, float eps, double* work) {
+                                                        int T, int64_t ss, int64_t bs, float eps, double* work,
+                                                        int plain_sdr = 0) {
     __shared__ float red[(S * S) * (NTH / 64)];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * CHUNK, t1 = min(t0 + CHUNK, T);
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(NTH) void pit_pass2_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < S; ++i)
 #pragma unroll
-        for (int j = 0; j < S; ++j) alpha[i * S + j] = (float)wb[i * S + j] / ((float)wb[S * S + j] + eps);
+        for (int j = 0; j < S; ++j)
+            alpha[i * S + j] = plain_sdr ? 1.f : (float)wb[i * S + j] / ((float)wb[S * S + j] + eps);
     float v[S * S];
 #pragma unroll
     for (int i = 0; i < S * S; ++i) v[i] = 0.f;
@@ -154,6 +156,52 @@ __global__ __launch_bounds__(NTH) void pit_bwd_kernel(const float* __restrict__ 
         a * tgt[(int64_t)b * bs + (int64_t)j * ss + t] + c * est[(int64_t)b * bs + (int64_t)i * ss + t];
 }
 
+// ------------------------------------------------------------------------------------------ pairwise matrix
+// Every pair's value and derivative, for criteria that need more than the winning assignment (Sinkhorn PIT) or the
+// plain SDR: pair[b][i][j] = SI-SDR(e_i, t_j) (kind 0) or SDR(e_i, t_j) = 10 log10((|t|^2 + eps) / (|t - e|^2 + eps))
+// (kind 1; src/criterion/sdr.py:19-20), and d pair / d e_i = ct * t_j + ce * e_i with (ct, ce) = paircoef[b][i][j].
+template <int S>
+__global__ void pair_finalize_kernel(const double* __restrict__ work, int batch, float eps, int kind, float* pair,
+                                     float* paircoef) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double* wb = work + (int64_t)b * (2 * S * S + S);
+    const double K = 10.0 / log(10.0);
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            const int64_t o = (int64_t)b * S * S + i * S + j;
+            const float dotf = (float)wb[i * S + j], ttf = (float)wb[S * S + j], resf = (float)wb[S * S + S + i * S + j];
+            const double dot = wb[i * S + j], tt = wb[S * S + j], den = wb[S * S + S + i * S + j] + (double)eps;
+            if (kind == 1) {
+                pair[o] = 10.f * log10f((ttf + eps) / (resf + eps));
+                paircoef[2 * o + 0] = (float)(2.0 * K / den);
+                paircoef[2 * o + 1] = (float)(-2.0 * K / den);
+            } else {
+                const float alpha = dotf / (ttf + eps);
+                pair[o] = 10.f * log10f((alpha * alpha * ttf + eps) / (resf + eps));
+                const double a = dot / (tt + (double)eps);
+                const double num = a * a * tt + (double)eps;
+                const double rt = -dot * (double)eps / (tt + (double)eps);
+                paircoef[2 * o + 0] = (float)(K * (2.0 * a * tt / ((tt + eps) * num) - 2.0 * rt / ((tt + eps) * den) + 2.0 * a / den));
+                paircoef[2 * o + 1] = (float)(-K * 2.0 / den);
+            }
+        }
+}
+
+// dest_i = sum_j A[b][i][j] t_j + C[b][i] e_i
+__global__ __launch_bounds__(NTH) void pair_bwd_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                       int S, int T, int64_t ss, int64_t bs,
+                                                       const float* __restrict__ A, const float* __restrict__ C,
+                                                       float* dest, int64_t dss, int64_t dbs) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int t = blockIdx.x * NTH + threadIdx.x;
+    if (t >= T) return;
+    float v = C[(int64_t)b * S + i] * est[(int64_t)b * bs + (int64_t)i * ss + t];
+    for (int j = 0; j < S; ++j)
+        v = __builtin_fmaf(A[((int64_t)b * S + i) * S + j], tgt[(int64_t)b * bs + (int64_t)j * ss + t], v);
+    dest[(int64_t)b * dbs + (int64_t)i * dss + t] = v;
+}
+
 // ------------------------------------------------------------------------------------------ optimizer
 __global__ __launch_bounds__(NTH) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* acc) {
     __shared__ float red[NTH / 64];
@@ -219,6 +267,36 @@ int ctn_pit_sisdr_bwd(const float* est, const float* tgt, int batch, int S, int 
     hipLaunchKernelGGL(pit_bwd_kernel, grid, dim3(NTH), 0, (hipStream_t)stream, est, tgt, S, T, ss, bs, perm, coef,
                        gscale, gs_bstride, gs_istride, dest, dss, dbs);
     CTN_CHECK_LAUNCH("ctn_pit_sisdr_bwd");
+    return CTN_OK;
+}
+
+int ctn_pair_sdr_fwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs, float eps,
+                     int kind, double* work, float* pair, float* paircoef, void* stream) {
+    CTN_REQUIRE(est && tgt && work && pair && paircoef, "ctn_pair_sdr_fwd: null pointer");
+    CTN_REQUIRE(batch > 0 && T > 0 && S >= 1 && S <= 4, "ctn_pair_sdr_fwd: supports 1..4 sources");
+    CTN_REQUIRE(kind == 0 || kind == 1, "ctn_pair_sdr_fwd: kind is 0 (SI-SDR) or 1 (SDR)");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ctn_cdiv(T, CHUNK), batch);
+#define CTN_PAIR_CASE(SS)                                                                                            \
+    case SS:                                                                                                         \
+        hipLaunchKernelGGL(pit_pass1_kernel<SS>, grid, dim3(NTH), 0, s, est, tgt, T, ss, bs, work);                  \
+        hipLaunchKernelGGL(pit_pass2_kernel<SS>, grid, dim3(NTH), 0, s, est, tgt, T, ss, bs, eps, work, kind);       \
+        hipLaunchKernelGGL(pair_finalize_kernel<SS>, dim3(ctn_cdiv(batch, 64)), dim3(64), 0, s, work, batch, eps,    \
+                           kind, pair, paircoef);                                                                    \
+        break;
+    switch (S) { CTN_PAIR_CASE(1) CTN_PAIR_CASE(2) CTN_PAIR_CASE(3) CTN_PAIR_CASE(4) }
+#undef CTN_PAIR_CASE
+    CTN_CHECK_LAUNCH("ctn_pair_sdr_fwd");
+    return CTN_OK;
+}
+
+int ctn_pair_sdr_bwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
+                     const float* A, const float* C, float* dest, int64_t dss, int64_t dbs, void* stream) {
+    CTN_REQUIRE(est && tgt && A && C && dest && batch > 0 && S >= 1 && T > 0, "ctn_pair_sdr_bwd: bad arguments");
+    dim3 grid(ctn_cdiv(T, NTH), S, batch);
+    hipLaunchKernelGGL(pair_bwd_kernel, grid, dim3(NTH), 0, (hipStream_t)stream, est, tgt, S, T, ss, bs, A, C, dest,
+                       dss, dbs);
+    CTN_CHECK_LAUNCH("ctn_pair_sdr_bwd");
     return CTN_OK;
 }
 

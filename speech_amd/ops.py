@@ -486,6 +486,33 @@ def pit_sisdr_bwd(est, tgt, perm, coef, gscale, gs_bstride, gs_istride):
     return dest
 
 
+PAIR_SISDR, PAIR_SDR = 0, 1
+
+
+def pair_sdr_fwd(est, tgt, eps, kind):
+    """est, tgt (B, S, T) contiguous, S <= 4.  Returns pair (B, S, S) = criterion(est_i, tgt_j) in dB (kind: PAIR_SISDR or
+    PAIR_SDR) and paircoef (B, S, S, 2), the coefficients of d pair / d est_i = ct * tgt_j + ce * est_i."""
+    lib = _lib.load()
+    B, S, T = est.shape
+    dev = est.device
+    work = torch.zeros((B, 2 * S * S + S), device=dev, dtype=torch.float64)
+    pair = torch.empty((B, S, S), device=dev, dtype=torch.float32)
+    paircoef = torch.empty((B, S, S, 2), device=dev, dtype=torch.float32)
+    _lib.check(lib.ctn_pair_sdr_fwd(_ptr(est), _ptr(tgt), B, S, T, est.stride(1), est.stride(0), eps, int(kind),
+                                    _ptr(work), _ptr(pair), _ptr(paircoef), _stream()), "ctn_pair_sdr_fwd")
+    return pair, paircoef
+
+
+def pair_sdr_bwd(est, tgt, A, Cc):
+    """dest_i = sum_j A[b, i, j] tgt_j + Cc[b, i] est_i."""
+    lib = _lib.load()
+    B, S, T = est.shape
+    dest = torch.empty((B, S, T), device=est.device, dtype=torch.float32)
+    _lib.check(lib.ctn_pair_sdr_bwd(_ptr(est), _ptr(tgt), B, S, T, est.stride(1), est.stride(0), _ptr(A), _ptr(Cc),
+                                    _ptr(dest), dest.stride(1), dest.stride(0), _stream()), "ctn_pair_sdr_bwd")
+    return dest
+
+
 def sumsq(g, acc):
     lib = _lib.load()
     _lib.check(lib.ctn_sumsq(_ptr(g), g.numel(), _ptr(acc), _stream()), "ctn_sumsq")

@@ -202,3 +202,31 @@ def test_dprnn_tasnet_surface_matches_reference(golden):
         DPRNNTasNet(**dict(dprnn_cases.SMALL, mask_nonlinear="tanh"))
     with pytest.raises(ValueError):
         DPRNNTasNet(**dict(dprnn_cases.SMALL, causal=False))(torch.zeros(3, 10))
+
+
+def test_criterion_variants_surface_and_no_cpu_fallback():
+    """SDR / NegSDR (src/criterion/sdr.py:24-114), ORPIT and SinkPIT (src/criterion/pit.py:87-213): constructor
+    arguments, the maximize flags, and the rule that the HIP criteria refuse CPU tensors instead of falling back."""
+    import inspect
+    from speech_amd._lib import CtnError
+    from speech_amd.criterion import pit as P, sdr as S
+    assert list(inspect.signature(S.NegSDR.__init__).parameters) == ["self", "reduction", "eps"]
+    assert list(inspect.signature(P.ORPIT.__init__).parameters) == ["self", "criterion"]
+    assert list(inspect.signature(P.SinkPIT.__init__).parameters) == ["self", "criterion", "n_sources", "coldness", "iteration"]
+    assert list(inspect.signature(P.sinkpit).parameters) == ["criterion", "input", "target", "n_sources", "coldness",
+                                                             "iteration", "batch_mean"]
+    assert S.SDR().maximize and not S.NegSDR().maximize and S.NegSDR().eps == 1e-12
+    assert P.ORPIT(S.NegSDR()).patterns.tolist() == [[0, 1], [1, 0]]
+    with pytest.raises(ValueError):
+        S.SDR(reduction="max")
+    e, t = torch.randn(2, 2, 64), torch.randn(2, 2, 64)
+    with pytest.raises(CtnError):
+        S.NegSDR()(e, t)
+    with pytest.raises(CtnError):
+        P.ORPIT(S.NegSISDR())(e, t)
+    # a criterion of the caller's own runs the generic routes on any device
+    mse = lambda a, b, batch_mean=True: ((a - b) ** 2).mean(dim=-1)
+    loss, P_ = P.sinkpit(mse, e, e[:, [1, 0]], coldness=50.0)
+    assert P_.argmax(dim=2).tolist() == [[1, 0], [1, 0]]
+    loss, idx = P.ORPIT(mse)(torch.stack([t[:, 1], t[:, 0]], dim=1), t, batch_mean=False)
+    assert idx.tolist() == [1, 1] and torch.allclose(loss, torch.zeros(2))

@@ -1,0 +1,112 @@
+"""The CPU restatement of the filterbank variants (oracle/filterbank_oracle.py) against the reference's own outputs
+(tests/golden/filterbank.npz): outputs within 1e-5, gradients within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+import convtasnet_oracle as O
+import filterbank_cases as FC
+import filterbank_oracle as FO
+from conftest import assert_close
+from speech_amd.utils import synth
+
+
+def params(g, prefix, grad=True):
+    out = {}
+    for k in g.files:
+        if k.startswith(prefix + "_p_"):
+            t = torch.from_numpy(g[k])
+            if grad and t.is_floating_point():
+                t.requires_grad_(True)
+            out[k[len(prefix) + 3:]] = t
+    return out
+
+
+def probe_backward(out):
+    real = torch.view_as_real(out) if torch.is_complex(out) else out
+    (real * synth.normal(tuple(real.shape), 977, std=1.0).to(real.device)).sum().backward()
+
+
+def as_real(t):
+    t = t.detach().cpu()
+    return torch.view_as_real(t) if torch.is_complex(t) else t
+
+
+def check(g, key, out, p, inputs, tol_out=1e-5, tol_grad=1e-4):
+    probe_backward(out)
+    assert_close(as_real(out), g[key + "_out"], tol_out, key)
+    for i, x in enumerate(inputs):
+        assert_close(as_real(x.grad), g[key + "_dx{}".format(i)], tol_grad, key + " dx")
+    n = 0
+    for k in g.files:
+        if k.startswith(key + "_g_"):
+            name = k[len(key) + 3:]
+            assert_close(p[name].grad, g[k], tol_grad, key + " grad " + name)
+            n += 1
+    return n
+
+
+@pytest.mark.parametrize("key", list(FC.FOURIER_ENCODERS))
+def test_fourier_encoder(golden, key):
+    g = golden("filterbank")
+    kw = FC.FOURIER_ENCODERS[key]
+    p = params(g, "fenc_" + key)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    out = FO.fourier_encode(x, p, FC.S, kw["onesided"], kw["return_complex"])
+    assert check(g, "fenc_" + key, out, p, [x]) >= 1
+
+
+@pytest.mark.parametrize("key", list(FC.FOURIER_DECODERS))
+def test_fourier_decoder(golden, key):
+    g = golden("filterbank")
+    kw, complex_in = FC.FOURIER_DECODERS[key]
+    p = params(g, "fdec_" + key)
+    z = FC.spectrum(synth, kw["onesided"], complex_in).requires_grad_(True)
+    out = FO.fourier_decode(z, p, FC.N_DFT, FC.S, kw["onesided"])
+    assert check(g, "fdec_" + key, out, p, [z]) >= 2
+
+
+def test_pinv_and_gated(golden):
+    g = golden("filterbank")
+    p = params(g, "pinv_trainable")
+    z = synth.normal((2, FC.N_PINV, FC.FRAMES), 311, std=0.5).requires_grad_(True)
+    out = FO.pinv_decode_trainable(z, p["weight"], FC.S)
+    probe_backward(out)
+    assert_close(out, g["pinv_trainable_out"], 1e-5, "pinv")
+    assert_close(z.grad, g["pinv_trainable_dx0"], 1e-4, "pinv dz")
+    # the reference reaches the one weight through two names (PinvDecoder.weight is encoder.conv1d.weight)
+    assert_close(p["weight"].grad, g["pinv_trainable_g_weight"], 1e-4, "pinv dW")
+
+    p = params(g, "pinv_fourier")
+    z = FC.spectrum(synth, False, False).requires_grad_(True)
+    out = FO.pinv_decode_fourier(z, {k[len("encoder."):]: v for k, v in p.items()}, FC.N_DFT, FC.S)
+    check(g, "pinv_fourier", out, p, [z])
+
+    p = params(g, "gated")
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    out = FO.gated_encode(x, p["conv1d_U.weight"], p["conv1d_V.weight"], FC.S)
+    assert check(g, "gated", out, p, [x]) == 2
+
+
+@pytest.mark.parametrize("key", list(FC.E2E))
+def test_conv_tasnet_with_filterbank_variants(golden, key):
+    g = golden("filterbank")
+    cfg = dict(FC.E2E_BASE, **FC.E2E[key])
+    sd = params(g, "e2e_" + key)
+    mixture, sources = synth.make_batch(2, cfg["n_sources"], FC.E2E_T, seed=321)
+    out = FO.conv_tasnet_forward(mixture, sd, cfg)
+    loss, perm = O.pit_neg_sisdr(out, sources)
+    loss.backward()
+    assert np.array_equal(perm.numpy(), g["e2e_" + key + "_perm"])
+    assert_close(out, g["e2e_" + key + "_out"], 1e-5, "waveforms")
+    assert_close(loss, g["e2e_" + key + "_loss"], 1e-5, "loss")
+    n = 0
+    for k in g.files:
+        if k.startswith("e2e_" + key + "_g_"):
+            name = k[len("e2e_" + key) + 3:]
+            if name == "decoder.weight" or name.startswith("decoder.encoder."):
+                continue            # aliases of encoder parameters inside PinvDecoder: the same tensor, counted once
+            assert sd[name].grad is not None, name
+            assert_close(sd[name].grad, g[k], 2e-4, "grad " + name)
+            n += 1
+    assert n > 20

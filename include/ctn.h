@@ -315,6 +315,21 @@ int ctn_encoder_bwd(const float* x, int64_t xbs, int Tin, int pad_left, int batc
                     float* dwt_out, int64_t lddwt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Depthwise Conv1d with arbitrary stride, dilation and zero padding: the depthwise half of the generic
+ * DepthwiseSeparableConv1d (src/modules/conv.py:13-29; nn.Conv1d(C, C, K, stride, padding, dilation, groups=C), default
+ * stride = kernel_size).  The TCN's stride-1 'same' layers use ctn_dw_fwd / ctn_dw_bwd instead.
+ * ------------------------------------------------------------------------------------------- */
+/* y[b][c][t] = bias[c] + sum_k w[c*K + k] * x[b][c][t*stride + k*dilation - pad_left]  (zero outside 0..Tin-1),
+ * t < Tout; rows of x / y at b*bs + c*ld.  bias may be null. */
+int ctn_dwconv_generic_fwd(const float* x, int64_t xbs, int64_t ldx, int batch, int C, int Tin, const float* w,
+                           const float* bias, int K, int stride, int dilation, int pad_left, float* y, int64_t ybs,
+                           int64_t ldy, int Tout, void* stream);
+/* dx (written, may be null), dW[C*K] and dbias[C] (accumulated into: zero them first; either may be null). */
+int ctn_dwconv_generic_bwd(const float* x, int64_t xbs, int64_t ldx, int batch, int C, int Tin, const float* w, int K,
+                           int stride, int dilation, int pad_left, const float* dy, int64_t dybs, int64_t lddy, int Tout,
+                           float* dx, int64_t dxbs, int64_t lddx, float* dW, float* dbias, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Utterance-level PIT SI-SDR (src/criterion/pit.py:9-44 over src/criterion/sdr.py:122-139,198-227)
  * ------------------------------------------------------------------------------------------- */
 /* work: double[batch * (2*S*S + S)] zeroed by the caller.  pair[b][i][j] = SI-SDR(est_i, tgt_j) in dB.

@@ -330,3 +330,17 @@ CONFIG_PAPER = dict(n_basis=512, kernel_size=16, stride=8, enc_nonlinear=None, s
                     sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3, sep_num_blocks=3,
                     sep_num_layers=8, mask_nonlinear="sigmoid", causal=False, n_sources=2, eps=EPS)
 CONFIG_CAUSAL3 = dict(CONFIG_PAPER, causal=True, n_sources=3)
+
+
+# --------------------------------------------------------------------------
+# generic depthwise separable convolution: src/modules/conv.py:13-29
+# --------------------------------------------------------------------------
+def depthwise_separable_conv1d(x, sd, kernel_size, stride=None, padding=0, dilation=1, prefix=""):
+    """DepthwiseSeparableConv1d.forward: src/modules/conv.py:25-29 -- depthwise Conv1d (groups = channels, stride
+    defaulting to the kernel size, :17-18) then a pointwise Conv1d, nothing in between."""
+    if stride is None:
+        stride = kernel_size
+    w = sd[prefix + "depthwise_conv1d.weight"]
+    y = F.conv1d(x, w, sd.get(prefix + "depthwise_conv1d.bias"), stride=stride, padding=padding, dilation=dilation,
+                 groups=w.shape[0])
+    return F.conv1d(y, sd[prefix + "pointwise_conv1d.weight"], sd.get(prefix + "pointwise_conv1d.bias"))

@@ -149,6 +149,10 @@ PROTOTYPES = {
                                     _p]),
     "ctn_pit_sisdr_bwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, C.c_int, C.c_int, _p,
                                     _i64, _i64, _p]),
+    "ctn_dwconv_generic_fwd": (C.c_int, [_p, _i64, _i64, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, _p, _i64, _i64, C.c_int, _p]),
+    "ctn_dwconv_generic_bwd": (C.c_int, [_p, _i64, _i64, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, _p, _i64, _i64, C.c_int, _p, _i64, _i64, _p, _p, _p]),
     "ctn_pair_sdr_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, _p, _p, _p, _p]),
     "ctn_pair_sdr_bwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _i64, _i64, _p]),
     "ctn_sumsq": (C.c_int, [_p, _i64, _p, _p]),

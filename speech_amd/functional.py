@@ -352,6 +352,31 @@ class DepthwiseFn(torch.autograd.Function):
         return dx, dw.view(weight.shape), db, None, None, None
 
 
+class DepthwiseGenericFn(torch.autograd.Function):
+    """Depthwise nn.Conv1d(C, C, K, stride, padding, dilation, groups=C) of any geometry (src/modules/conv.py:22,26)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, dilation, padding):
+        x = as_act(x.detach().float())
+        B, Cc, T = x.shape
+        K = weight.shape[-1]
+        Tout = (T + 2 * padding - dilation * (K - 1) - 1) // stride + 1
+        if Tout < 1:
+            raise RuntimeError("Calculated padded input size per channel: ({}). Kernel size: ({}). Kernel size can't be "
+                               "greater than actual input size".format(T + 2 * padding, dilation * (K - 1) + 1))
+        w = weight.detach().reshape(Cc, K).contiguous().float()
+        y = ops.dwconv_generic_fwd(x, w, None if bias is None else bias.detach().float(), stride, dilation, padding, Tout)
+        ctx.saved = (x, w, weight.shape, bias is not None, stride, dilation, padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, wshape, has_bias, stride, dilation, padding = ctx.saved
+        dx, dW, db = ops.dwconv_generic_bwd(x, w, as_act(dy), stride, dilation, padding, ctx.needs_input_grad[0],
+                                            has_bias)
+        return dx, dW.view(wshape), db, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ encoder / decoder
 def _enc_geometry(T, L, S):
     padding = (S - (T - L) % S) % S                   # src/models/conv_tasnet.py:145

@@ -2,7 +2,7 @@
 depthwise Conv1d -> pointwise Conv1d, nothing in between, on the HIP depthwise and MFMA kernels."""
 import torch.nn as nn
 
-from ..functional import Conv1x1Fn, DepthwiseFn
+from ..functional import Conv1x1Fn, DepthwiseFn, DepthwiseGenericFn
 
 
 class DepthwiseSeparableConv1d(nn.Module):
@@ -18,20 +18,14 @@ class DepthwiseSeparableConv1d(nn.Module):
         self.pointwise_conv1d = nn.Conv1d(in_channels, out_channels, kernel_size=1, stride=1, bias=bias)
 
     def forward(self, input):
-        if self.stride != 1:
-            raise NotImplementedError("HIP depthwise kernel: stride 1 only (given {})".format(self.stride))
         pad = self.padding if isinstance(self.padding, int) else self.padding[0]
+        stride = self.stride if isinstance(self.stride, int) else self.stride[0]
         span = (self.kernel_size - 1) * self.dilation
         dw = self.depthwise_conv1d
-        if 2 * pad == span:
+        if stride == 1 and 2 * pad == span:
+            # 'same' length at stride 1: the tiled kernel of the TCN layers
             x = DepthwiseFn.apply(input, dw.weight, dw.bias, self.dilation, pad, pad)
-        elif 2 * pad < span:
-            # output shorter than the input: run at the input length with the taps anchored at
-            # -pad and keep the first T + 2*pad - span frames
-            T = input.size(-1)
-            x = DepthwiseFn.apply(input, dw.weight, dw.bias, self.dilation, pad, span - pad)
-            x = x[..., :T + 2 * pad - span]
         else:
-            raise NotImplementedError("HIP depthwise kernel: padding larger than 'same' is not supported")
+            x = DepthwiseGenericFn.apply(input, dw.weight, dw.bias, stride, self.dilation, pad)
         pw = self.pointwise_conv1d
         return Conv1x1Fn.apply(x, pw.weight, pw.bias)

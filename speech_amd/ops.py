@@ -486,6 +486,31 @@ def pit_sisdr_bwd(est, tgt, perm, coef, gscale, gs_bstride, gs_istride):
     return dest
 
 
+def dwconv_generic_fwd(x, w, bias, stride, dilation, pad_left, Tout):
+    """x (B, C, Tin) with unit time stride, w (C, K) -> y (B, C, Tout): depthwise convolution of any geometry."""
+    lib = _lib.load()
+    B, Cc, Tin = x.shape
+    y = new_act(B, Cc, Tout, x.device)
+    _lib.check(lib.ctn_dwconv_generic_fwd(_ptr(x), x.stride(0), x.stride(1), B, Cc, Tin, _ptr(w), _ptr(bias), w.shape[1],
+                                          stride, dilation, pad_left, _ptr(y), y.stride(0), y.stride(1), Tout, _stream()),
+               "ctn_dwconv_generic_fwd")
+    return y
+
+
+def dwconv_generic_bwd(x, w, dy, stride, dilation, pad_left, need_dx, need_db):
+    lib = _lib.load()
+    B, Cc, Tin = x.shape
+    Tout = dy.shape[2]
+    dx = new_act(B, Cc, Tin, x.device) if need_dx else None
+    dW = torch.zeros_like(w)
+    db = torch.zeros((Cc,), device=x.device, dtype=torch.float32) if need_db else None
+    _lib.check(lib.ctn_dwconv_generic_bwd(_ptr(x), x.stride(0), x.stride(1), B, Cc, Tin, _ptr(w), w.shape[1], stride,
+                                          dilation, pad_left, _ptr(dy), dy.stride(0), dy.stride(1), Tout, _ptr(dx),
+                                          dx.stride(0) if need_dx else 0, dx.stride(1) if need_dx else 0, _ptr(dW),
+                                          _ptr(db), _stream()), "ctn_dwconv_generic_bwd")
+    return dx, dW, db
+
+
 PAIR_SISDR, PAIR_SDR = 0, 1
 
 

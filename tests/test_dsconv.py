@@ -1,0 +1,67 @@
+"""The generic DepthwiseSeparableConv1d (src/modules/conv.py:13-29) over strides, paddings and dilations, against the
+reference's own outputs (tests/golden/dsconv.npz): the CPU oracle within 1e-5, the HIP module within 1e-4 (forward and
+every gradient)."""
+import pytest
+import torch
+
+import convtasnet_oracle as O
+from conftest import assert_close
+from dsconv_cases import CASES
+from speech_amd.utils import synth
+
+
+def build_state(ci, co, K, bias):
+    sd = {"depthwise_conv1d.weight": torch.empty(ci, 1, K), "pointwise_conv1d.weight": torch.empty(co, ci, 1)}
+    if bias:
+        sd["depthwise_conv1d.bias"] = torch.empty(ci)
+        sd["pointwise_conv1d.bias"] = torch.empty(co)
+    # same order as the module's state_dict: weight, bias per layer
+    order = ["depthwise_conv1d.weight", "depthwise_conv1d.bias", "pointwise_conv1d.weight", "pointwise_conv1d.bias"]
+    sd = {k: sd[k] for k in order if k in sd}
+    return synth.fill_parameters(sd, salt=9)
+
+
+@pytest.mark.parametrize("key", list(CASES))
+def test_oracle_vs_reference(golden, key):
+    g = golden("dsconv")
+    ci, co, K, stride, pad, dil, bias, T = CASES[key]
+    i = list(CASES).index(key)
+    sd = {k: v.requires_grad_(True) for k, v in build_state(ci, co, K, bias).items()}
+    x = synth.normal((2, ci, T), 400 + i, std=0.5).requires_grad_(True)
+    y = O.depthwise_separable_conv1d(x, sd, K, stride, pad, dil)
+    (y * synth.normal(tuple(y.shape), 450 + i)).sum().backward()
+    assert tuple(y.shape) == g[key + "_y"].shape
+    assert_close(y, g[key + "_y"], 1e-5, key)
+    assert_close(x.grad, g[key + "_dx"], 1e-5, key + " dx")
+    for name, p in sd.items():
+        assert_close(p.grad, g[key + "_g_" + name], 1e-5, key + " grad " + name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", list(CASES))
+def test_hip_module_vs_reference(golden, key):
+    from speech_amd.modules.conv import DepthwiseSeparableConv1d
+    g = golden("dsconv")
+    ci, co, K, stride, pad, dil, bias, T = CASES[key]
+    i = list(CASES).index(key)
+    dev = torch.device("cuda:0")
+    m = DepthwiseSeparableConv1d(ci, co, K, stride=stride, padding=pad, dilation=dil, bias=bias)
+    assert list(m.state_dict().keys()) == list(build_state(ci, co, K, bias).keys())
+    synth.fill_parameters(m, salt=9)
+    m = m.to(dev)
+    x = synth.normal((2, ci, T), 400 + i, std=0.5).to(dev).requires_grad_(True)
+    y = m(x)
+    (y * synth.normal(tuple(y.shape), 450 + i).to(dev)).sum().backward()
+    assert tuple(y.shape) == g[key + "_y"].shape
+    assert_close(y, g[key + "_y"], 1e-4, key)
+    assert_close(x.grad, g[key + "_dx"], 1e-4, key + " dx")
+    for name, p in m.named_parameters():
+        assert_close(p.grad, g[key + "_g_" + name], 1e-4, key + " grad " + name)
+
+
+@pytest.mark.gpu
+def test_kernel_longer_than_input_raises():
+    from speech_amd.modules.conv import DepthwiseSeparableConv1d
+    m = DepthwiseSeparableConv1d(4, 4, 9, stride=2).to("cuda:0")
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 5, device="cuda:0"))

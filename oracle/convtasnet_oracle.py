@@ -85,7 +85,7 @@ def decoder(w_hat, weight, stride):
 # --------------------------------------------------------------------------
 # TCN: src/models/tdcn.py
 # --------------------------------------------------------------------------
-def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, eps=EPS):
+def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, eps=EPS, stride=1):
     """ResidualBlock1d.forward (separable, prelu, norm): src/models/tdcn.py:107-147,
     with the dual-head DepthwiseSeparableConv1d of tdcn.py:177-196 inlined."""
     T = x.shape[-1]
@@ -93,7 +93,7 @@ def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, ep
     y = F.conv1d(x, sd[prefix + "bottleneck_conv1d.weight"], sd[prefix + "bottleneck_conv1d.bias"])  # :116
     y = F.prelu(y, sd[prefix + "nonlinear1d.weight"])                                               # :119
     y = layer_norm(y, sd, prefix + "norm1d.", causal, eps)                                          # :121
-    padding = (kernel_size - 1) * dilation                                                          # :123 (stride 1)
+    padding = (T - 1) * stride - T + (kernel_size - 1) * dilation + 1                               # :123
     if causal:
         pad_l, pad_r = padding, 0                                                                   # :125-127
     else:
@@ -103,7 +103,7 @@ def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, ep
     sp = prefix + "separable_conv1d."
     H = y.shape[1]
     y = F.conv1d(y, sd[sp + "depthwise_conv1d.weight"], sd[sp + "depthwise_conv1d.bias"],
-                 dilation=dilation, groups=H)                                                       # :181
+                 stride=stride, dilation=dilation, groups=H)                                        # :181
     y = F.prelu(y, sd[sp + "nonlinear1d.weight"])                                                   # :184
     y = layer_norm(y, sd, sp + "norm1d.", causal, eps)                                              # :187
     if dual_head:
@@ -116,16 +116,17 @@ def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, ep
     return out, skip
 
 
-def tdcn(x, sd, prefix, num_blocks, num_layers, causal, kernel_size=3, eps=EPS):
+def tdcn(x, sd, prefix, num_blocks, num_layers, causal, kernel_size=3, eps=EPS, dilated=True):
     """TimeDilatedConvNet.forward + TimeDilatedConvBlock1d.forward: src/models/tdcn.py:29-41, :65-75.
-    Dilation 2**layer (:53); the very last layer has no residual head (:22-23, :58-59)."""
+    Dilation 2**layer at stride 1 (:52-54), or dilation 1 at stride 2 when not dilated (:55-57); the very last layer has
+    no residual head (:22-23, :58-59)."""
     skip_total = 0
     for r in range(num_blocks):
         block_skip = 0
         for l in range(num_layers):
             dual = not (r == num_blocks - 1 and l == num_layers - 1)
-            x, skip = residual_block(x, sd, "{}net.{}.net.{}.".format(prefix, r, l), 2 ** l, causal, dual,
-                                     kernel_size, eps)
+            x, skip = residual_block(x, sd, "{}net.{}.net.{}.".format(prefix, r, l), 2 ** l if dilated else 1, causal,
+                                     dual, kernel_size, eps, stride=1 if dilated else 2)
             block_skip = block_skip + skip
         skip_total = skip_total + block_skip
     return skip_total
@@ -142,7 +143,7 @@ def separator(w, sd, cfg, prefix="separator."):
     x = layer_norm(w, sd, prefix + "norm1d.", causal, eps)                                          # :370
     x = F.conv1d(x, sd[prefix + "bottleneck_conv1d.weight"], sd[prefix + "bottleneck_conv1d.bias"])  # :371
     x = tdcn(x, sd, prefix + "tdcn.", cfg["sep_num_blocks"], cfg["sep_num_layers"], causal,
-             cfg.get("sep_kernel_size", 3), eps)                                                    # :372
+             cfg.get("sep_kernel_size", 3), eps, dilated=cfg.get("dilated", True))                  # :372
     x = F.prelu(x, sd[prefix + "prelu.weight"])                                                     # :373
     x = F.conv1d(x, sd[prefix + "mask_conv1d.weight"], sd[prefix + "mask_conv1d.bias"])             # :374
     if cfg.get("mask_nonlinear", "sigmoid") == "sigmoid":

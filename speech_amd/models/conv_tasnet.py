@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import ConvTasNetFn, SeparatorFn, Layer
+from ..functional import ConvTasNetFn, SeparatorFn, Layer, LayerNormFn, Conv1x1Fn
 from ..utils.filterbank import choose_filterbank
 from ..utils.model import choose_nonlinear
 from ..utils.tasnet import choose_layer_norm
@@ -224,7 +224,8 @@ class Separator(nn.Module):
         self.num_features, self.n_sources = num_features, n_sources
         self.num_blocks, self.num_layers = num_blocks, num_layers
         self.causal, self.eps = causal, eps
-        self.hip_ok = dilated and separable and nonlinear == 'prelu' and norm
+        self.hip_ok = separable and nonlinear == 'prelu' and norm
+        self.dilated = dilated
 
         norm_name = 'cLN' if causal else 'gLN'
         self.norm1d = choose_layer_norm(norm_name, num_features, causal=causal, eps=eps)
@@ -259,9 +260,19 @@ class Separator(nn.Module):
             output (batch_size, n_sources, n_basis, n_frames)
         """
         if not self.hip_ok:
-            raise NotImplementedError("HIP path: Separator needs dilated, separable, prelu and norm")
+            raise NotImplementedError("HIP path: Separator needs separable, prelu and norm")
         num_features, n_sources = self.num_features, self.n_sources
         batch_size, _, n_frames = input.size()
+        if not self.dilated:
+            # stride-2 layers (src/models/tdcn.py:55-57): module by module, conv_tasnet.py:360-376
+            g0, be0 = _norm_params(self.norm1d)
+            x = LayerNormFn.apply(input, g0, be0, self.eps, self.causal)
+            x = Conv1x1Fn.apply(x, self.bottleneck_conv1d.weight, self.bottleneck_conv1d.bias)
+            x = self.tdcn(x)
+            x = F.prelu(x, self.prelu.weight)
+            x = Conv1x1Fn.apply(x, self.mask_conv1d.weight, self.mask_conv1d.bias)
+            x = self.mask_nonlinear(x)
+            return x.reshape(batch_size, n_sources, num_features, n_frames)
         cfg = dict(sep_num_blocks=self.num_blocks, sep_num_layers=self.num_layers, causal=self.causal,
                    n_sources=n_sources, eps=self.eps)
         g0, be0 = _norm_params(self.norm1d)

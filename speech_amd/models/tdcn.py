@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import ResidualBlockFn, LayerNormFn, Conv1x1Fn, DepthwiseFn
+from ..functional import ResidualBlockFn, LayerNormFn, Conv1x1Fn, DepthwiseFn, DepthwiseGenericFn
 from ..utils.tasnet import choose_layer_norm
 
 EPS = 1e-12
@@ -120,10 +120,27 @@ class ResidualBlock1d(nn.Module):
         return ps
 
     def forward(self, input):
-        if not self.hip_supported():
-            raise NotImplementedError("HIP path: ResidualBlock1d needs stride=1, separable, prelu and norm")
-        output, skip = ResidualBlockFn.apply(input, self.dilation, self.causal, self.dual_head, self.eps,
-                                             *self.parameter_list())
+        if self.hip_supported():
+            output, skip = ResidualBlockFn.apply(input, self.dilation, self.causal, self.dual_head, self.eps,
+                                                 *self.parameter_list())
+            return output, skip
+        if not (self.separable and self.nonlinear and self.norm):
+            raise NotImplementedError("HIP path: ResidualBlock1d needs separable, prelu and norm")
+        # strided (non-dilated) layers, src/models/tdcn.py:55-57: stage by stage on the same kernels; the padding keeps
+        # the frame count (:123-132), so most of what the stride-2 depthwise convolution reads is zero padding
+        kernel_size, stride, dilation = self.kernel_size, self.stride, self.dilation
+        T_original = input.size(-1)
+        b = self.bottleneck_conv1d
+        x = Conv1x1Fn.apply(input, b.weight, b.bias)
+        x = F.prelu(x, self.nonlinear1d.weight)
+        g, be = _norm_params(self.norm1d)
+        x = LayerNormFn.apply(x, g, be, self.eps, self.causal)
+        padding = (T_original - 1) * stride - T_original + (kernel_size - 1) * dilation + 1
+        padding_left = padding if self.causal else padding // 2
+        x = F.pad(x, (padding_left, padding - padding_left))
+        output, skip = self.separable_conv1d(x)
+        if output is not None:
+            output = output + input
         return output, skip
 
 
@@ -159,12 +176,13 @@ class DepthwiseSeparableConv1d(nn.Module):
         self.skip_pointwise_conv1d = nn.Conv1d(in_channels, skip_channels, kernel_size=1, stride=1)
 
     def forward(self, input):
-        if self.stride != 1:
-            raise NotImplementedError("HIP depthwise kernel: stride 1 only")
         span = (self.kernel_size - 1) * self.dilation
         T_out = input.size(-1) - span
         dw = self.depthwise_conv1d
-        x = DepthwiseFn.apply(input, dw.weight, dw.bias, self.dilation, 0, span)[..., :T_out]
+        if self.stride == 1:
+            x = DepthwiseFn.apply(input, dw.weight, dw.bias, self.dilation, 0, span)[..., :T_out]
+        else:
+            x = DepthwiseGenericFn.apply(input, dw.weight, dw.bias, self.stride, self.dilation, 0)
         if self.nonlinear:
             x = F.prelu(x, self.nonlinear1d.weight)
         if self.norm:

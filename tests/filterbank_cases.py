@@ -28,6 +28,8 @@ E2E = {
                     enc_return_complex=False, window_fn="hann"),
     "pinv": dict(enc_basis="trainable", dec_basis="pinv"),
     "gated": dict(enc_basis="trainableGated", dec_basis="trainable"),
+    "nondilated": dict(enc_basis="trainable", dec_basis="trainable", dilated=False, sep_num_layers=3),
+    "nondilated_causal": dict(enc_basis="trainable", dec_basis="trainable", dilated=False, causal=True, enc_nonlinear="relu"),
     "fourier_pinv": dict(enc_basis="trainableFourier", dec_basis="pinv", enc_onesided=False, enc_return_complex=False,
                          window_fn="hann"),
 }

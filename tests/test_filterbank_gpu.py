@@ -127,7 +127,7 @@ def test_conv_tasnet_with_filterbank_variants(golden, key):
                        enc_onesided=cfg.get("enc_onesided"), enc_return_complex=cfg.get("enc_return_complex"),
                        sep_hidden_channels=cfg["sep_hidden_channels"], sep_bottleneck_channels=cfg["sep_bottleneck_channels"],
                        sep_skip_channels=cfg["sep_skip_channels"], sep_kernel_size=cfg["sep_kernel_size"],
-                       sep_num_blocks=cfg["sep_num_blocks"], sep_num_layers=cfg["sep_num_layers"], dilated=True,
+                       sep_num_blocks=cfg["sep_num_blocks"], sep_num_layers=cfg["sep_num_layers"], dilated=cfg.get("dilated", True),
                        separable=True, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear=cfg["mask_nonlinear"],
                        causal=cfg["causal"], n_sources=cfg["n_sources"])
     assert list(model.state_dict().keys()) == [str(k) for k in g["e2e_" + key + "_keys"]]

@@ -103,7 +103,7 @@ def main():
                            sep_bottleneck_channels=cfg["sep_bottleneck_channels"],
                            sep_skip_channels=cfg["sep_skip_channels"], sep_kernel_size=cfg["sep_kernel_size"],
                            sep_num_blocks=cfg["sep_num_blocks"], sep_num_layers=cfg["sep_num_layers"],
-                           dilated=True, separable=True, sep_nonlinear="prelu", sep_norm=True,
+                           dilated=cfg.get("dilated", True), separable=True, sep_nonlinear="prelu", sep_norm=True,
                            mask_nonlinear=cfg["mask_nonlinear"], causal=cfg["causal"], n_sources=cfg["n_sources"])
         FC.fill_model(model, synth)
         mixture, sources = synth.make_batch(2, cfg["n_sources"], FC.E2E_T, seed=321)

@@ -83,27 +83,40 @@ def sub(sd, prefix):
 
 def conv_tasnet_forward(x, sd, cfg):
     """ConvTasNet.extract_latent (src/models/conv_tasnet.py:121-171) with the filterbank chosen as
-    src/utils/filterbank.py:5-46 does from cfg['enc_basis'] / cfg['dec_basis']."""
+    src/utils/filterbank.py:5-46 does from cfg['enc_basis'] / cfg['dec_basis']; 4-D input (B, 1, n_mics, T) is viewed
+    as n_mics input channels (:138-141), a complex latent is masked in magnitude with its phase kept (:152-156)."""
+    n_mics = None
+    if x.dim() == 4:
+        n_mics = x.shape[2]
+        x = x.reshape(x.shape[0], n_mics, x.shape[3])
     B, _, T = x.shape
     L = cfg["kernel_size"]
     S = cfg.get("stride") or L // 2
     n_src, N = cfg["n_sources"], cfg["n_basis"]
     eb, db = cfg["enc_basis"], cfg["dec_basis"]
-    onesided = bool(cfg.get("enc_onesided"))
+    onesided, cplx = bool(cfg.get("enc_onesided")), bool(cfg.get("enc_return_complex"))
     padding = (S - (T - L) % S) % S
     pad_l = padding // 2
     pad_r = padding - pad_l
     xp = F.pad(x, (pad_l, pad_r))
-    if eb in FOURIER or db in FOURIER:
-        n_dft = 2 * (N // 2 - 1) if onesided else N // 2            # compute_valid_basis, return_complex=False
+    if eb in FOURIER or db in FOURIER:      # compute_valid_basis, src/utils/filterbank.py:52-67
+        if onesided:
+            n_dft = 2 * (N - 1) if cplx else 2 * (N // 2 - 1)
+        else:
+            n_dft = N if cplx else N // 2
     if eb == "trainable":
         w = O.encoder(xp, sd["encoder.conv1d.weight"], S, None if db == "pinv" else cfg.get("enc_nonlinear"))
     elif eb in FOURIER:
-        w = fourier_encode(xp, sub(sd, "encoder."), S, onesided, False)
+        w = fourier_encode(xp, sub(sd, "encoder."), S, onesided, cplx)
     elif eb == "trainableGated":
         w = gated_encode(xp, sd["encoder.conv1d_U.weight"], sd["encoder.conv1d_V.weight"], S, cfg.get("eps", EPS))
-    mask = O.separator(w, sd, cfg)
-    w_hat = (w.unsqueeze(1) * mask).reshape(B * n_src, N, -1)
+    if torch.is_complex(w):
+        amplitude, phase = torch.abs(w), torch.angle(w)
+        mask = O.separator(amplitude, sd, cfg)
+        w_hat = amplitude.unsqueeze(1) * mask * torch.exp(1j * phase.unsqueeze(1))
+    else:
+        w_hat = w.unsqueeze(1) * O.separator(w, sd, cfg)
+    w_hat = w_hat.reshape(B * n_src, N, -1)
     if db == "trainable":
         x_hat = O.decoder(w_hat, sd["decoder.conv_transpose1d.weight"], S)
     elif db in FOURIER:
@@ -112,4 +125,5 @@ def conv_tasnet_forward(x, sd, cfg):
         x_hat = pinv_decode_trainable(w_hat, sd["encoder.conv1d.weight"], S)
     else:
         x_hat = pinv_decode_fourier(w_hat, sub(sd, "encoder."), n_dft, S)
-    return F.pad(x_hat.view(B, n_src, -1), (-pad_l, -pad_r))
+    x_hat = x_hat.view(B, n_src, -1) if n_mics is None else x_hat.view(B, n_src, n_mics, -1)
+    return F.pad(x_hat, (-pad_l, -pad_r))

@@ -133,9 +133,14 @@ class ConvTasNet(nn.Module):
 
         input = F.pad(input, (padding_left, padding_right))
         w = self.encoder(input)
-        mask = self.separator(w)
-        w = w.unsqueeze(dim=1)
-        w_hat = w * mask
+        if torch.is_complex(w):     # complex Fourier latent: the mask scales the magnitude, the phase is kept (:152-156)
+            amplitude, phase = torch.abs(w), torch.angle(w)
+            mask = self.separator(amplitude)
+            w_hat = amplitude.unsqueeze(dim=1) * mask * torch.exp(1j * phase.unsqueeze(dim=1))
+        else:
+            mask = self.separator(w)
+            w = w.unsqueeze(dim=1)
+            w_hat = w * mask
 
         latent = w_hat
         w_hat = w_hat.reshape(batch_size * n_sources, n_basis, -1)

@@ -12,6 +12,17 @@ from ..utils.audio import build_window, build_optimal_window
 EPS = 1e-12
 
 
+def _analysis(input, weight, stride, relu):
+    """Conv1d(in_channels, N, L, stride, bias=False) on the one-channel HIP encoder kernel: a sum over the input
+    channels (microphones), the ReLU after the sum."""
+    if input.size(1) == 1:
+        return EncoderFn.apply(input, weight, stride, relu)
+    x = EncoderFn.apply(input[:, 0:1], weight[:, 0:1].contiguous(), stride, False)
+    for c in range(1, input.size(1)):
+        x = x + EncoderFn.apply(input[:, c:c + 1], weight[:, c:c + 1].contiguous(), stride, False)
+    return torch.relu(x) if relu else x
+
+
 class Encoder(nn.Module):
     def __init__(self, in_channels, n_basis, kernel_size=16, stride=8, nonlinear=None):
         super().__init__()
@@ -28,7 +39,7 @@ class Encoder(nn.Module):
             self.nonlinear = False
 
     def forward(self, input):
-        return EncoderFn.apply(input, self.conv1d.weight, self.stride, self.nonlinear)
+        return _analysis(input, self.conv1d.weight, self.stride, self.nonlinear)
 
     def get_basis(self):
         return self.conv1d.weight
@@ -38,14 +49,17 @@ class Decoder(nn.Module):
     def __init__(self, n_basis, out_channels, kernel_size=16, stride=8):
         super().__init__()
         self.kernel_size, self.stride = kernel_size, stride
-        if out_channels != 1:
-            raise NotImplementedError("HIP decoder supports out_channels == 1")
         # parameter container: state_dict key `conv_transpose1d.weight` (N, 1, L)
         self.conv_transpose1d = nn.ConvTranspose1d(n_basis, out_channels, kernel_size=kernel_size, stride=stride,
                                                    bias=False)
 
     def forward(self, input):
-        return DecoderFn.apply(input, self.conv_transpose1d.weight, self.stride)
+        weight = self.conv_transpose1d.weight                      # (N, out_channels, L)
+        if weight.size(1) == 1:
+            return DecoderFn.apply(input, weight, self.stride)
+        # one overlap-add pass per output channel (microphone)
+        return torch.cat([DecoderFn.apply(input, weight[:, c:c + 1].contiguous(), self.stride)
+                          for c in range(weight.size(1))], dim=1)
 
     def get_basis(self):
         return self.conv_transpose1d.weight
@@ -226,6 +240,6 @@ class GatedEncoder(nn.Module):
     def forward(self, input):
         norm = torch.linalg.norm(input, dim=2, keepdim=True)
         x = input / (norm + self.eps)
-        x_U = EncoderFn.apply(x, self.conv1d_U.weight, self.stride, True)
-        x_V = EncoderFn.apply(x, self.conv1d_V.weight, self.stride, False)
+        x_U = _analysis(x, self.conv1d_U.weight, self.stride, True)
+        x_V = _analysis(x, self.conv1d_V.weight, self.stride, False)
         return x_U * self.sigmoid(x_V)

@@ -30,6 +30,9 @@ E2E = {
     "gated": dict(enc_basis="trainableGated", dec_basis="trainable"),
     "nondilated": dict(enc_basis="trainable", dec_basis="trainable", dilated=False, sep_num_layers=3),
     "nondilated_causal": dict(enc_basis="trainable", dec_basis="trainable", dilated=False, causal=True, enc_nonlinear="relu"),
+    "multimic": dict(enc_basis="trainable", dec_basis="trainable", in_channels=2, enc_nonlinear="relu"),
+    "fourier_complex": dict(enc_basis="Fourier", dec_basis="Fourier", enc_onesided=True, enc_return_complex=True,
+                            window_fn="hann", n_basis=33),
     "fourier_pinv": dict(enc_basis="trainableFourier", dec_basis="pinv", enc_onesided=False, enc_return_complex=False,
                          window_fn="hann"),
 }
@@ -61,3 +64,13 @@ def fill_model(model, synth):
     state = {k: v for k, v in model.state_dict().items() if k.split(".")[-1] not in FOURIER_LEAVES}
     synth.fill_parameters(state, salt=2)
     perturb(model, synth, salt=1)
+
+
+def e2e_batch(synth, cfg):
+    """Mixture and sources of an end-to-end case: (2, 1, T) / (2, n_sources, T), or with a microphone axis
+    (2, 1, n_mics, T) / (2, n_sources, n_mics, T) when the model takes several input channels."""
+    n_mics = cfg.get("in_channels") or 1
+    if n_mics == 1:
+        return synth.make_batch(2, cfg["n_sources"], E2E_T, seed=321)
+    sources = synth.normal((2, cfg["n_sources"], n_mics, E2E_T), 322, std=0.1)
+    return sources.sum(dim=1, keepdim=True), sources

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import convtasnet_oracle as O
+import criterion_oracle as CO
 import filterbank_cases as FC
 import filterbank_oracle as FO
 from conftest import assert_close
@@ -93,9 +94,10 @@ def test_conv_tasnet_with_filterbank_variants(golden, key):
     g = golden("filterbank")
     cfg = dict(FC.E2E_BASE, **FC.E2E[key])
     sd = params(g, "e2e_" + key)
-    mixture, sources = synth.make_batch(2, cfg["n_sources"], FC.E2E_T, seed=321)
+    mixture, sources = FC.e2e_batch(synth, cfg)
     out = FO.conv_tasnet_forward(mixture, sd, cfg)
-    loss, perm = O.pit_neg_sisdr(out, sources)
+    crit = CO.Criterion(CO.sisdr, negate=True)            # reduces over sources and microphones, src/criterion/sdr.py:212-222
+    loss, perm = O.pit(crit, out, sources)
     loss.backward()
     assert np.array_equal(perm.numpy(), g["e2e_" + key + "_perm"])
     assert_close(out, g["e2e_" + key + "_out"], 1e-5, "waveforms")

@@ -123,7 +123,8 @@ def test_conv_tasnet_with_filterbank_variants(golden, key):
     g = golden("filterbank")
     cfg = dict(FC.E2E_BASE, **FC.E2E[key])
     model = ConvTasNet(cfg["n_basis"], cfg["kernel_size"], stride=cfg["stride"], enc_basis=cfg["enc_basis"],
-                       dec_basis=cfg["dec_basis"], enc_nonlinear=cfg.get("enc_nonlinear"), window_fn=cfg.get("window_fn"),
+                       dec_basis=cfg["dec_basis"], enc_nonlinear=cfg.get("enc_nonlinear"),
+                       in_channels=cfg.get("in_channels") or 1, window_fn=cfg.get("window_fn"),
                        enc_onesided=cfg.get("enc_onesided"), enc_return_complex=cfg.get("enc_return_complex"),
                        sep_hidden_channels=cfg["sep_hidden_channels"], sep_bottleneck_channels=cfg["sep_bottleneck_channels"],
                        sep_skip_channels=cfg["sep_skip_channels"], sep_kernel_size=cfg["sep_kernel_size"],
@@ -132,7 +133,7 @@ def test_conv_tasnet_with_filterbank_variants(golden, key):
                        causal=cfg["causal"], n_sources=cfg["n_sources"])
     assert list(model.state_dict().keys()) == [str(k) for k in g["e2e_" + key + "_keys"]]
     load(model, g, "e2e_" + key)
-    mixture, sources = synth.make_batch(2, cfg["n_sources"], FC.E2E_T, seed=321)
+    mixture, sources = FC.e2e_batch(synth, cfg)
     out = model(mixture.to(dev()))
     loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))
     loss.backward()

@@ -1,6 +1,6 @@
 """Generate tests/golden/filterbank.npz by running the REFERENCE's own filterbank modules and ConvTasNet on CPU:
 Fourier encoder / decoder (one- and two-sided, real and complex, trainable frequency and phase), pseudo-inverse
-decoders, the gated encoder, and ConvTasNet forward + loss + gradients with three non-default filterbank pairs.
+decoders, the gated encoder, and ConvTasNet forward + loss + gradients with non-default filterbank pairs, the non-dilated TCN, two microphones and a complex latent.
 Runs only in the build container (needs /root/reference); the fixture holds plain arrays.
 
     PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_filterbank.py
@@ -97,7 +97,7 @@ def main():
         cfg = dict(FC.E2E_BASE, **extra)
         model = ConvTasNet(cfg["n_basis"], cfg["kernel_size"], stride=cfg["stride"], enc_basis=cfg["enc_basis"],
                            dec_basis=cfg["dec_basis"], enc_nonlinear=cfg.get("enc_nonlinear"),
-                           window_fn=cfg.get("window_fn"), enc_onesided=cfg.get("enc_onesided"),
+                           in_channels=cfg.get("in_channels") or 1, window_fn=cfg.get("window_fn"), enc_onesided=cfg.get("enc_onesided"),
                            enc_return_complex=cfg.get("enc_return_complex"),
                            sep_hidden_channels=cfg["sep_hidden_channels"],
                            sep_bottleneck_channels=cfg["sep_bottleneck_channels"],
@@ -106,7 +106,7 @@ def main():
                            dilated=cfg.get("dilated", True), separable=True, sep_nonlinear="prelu", sep_norm=True,
                            mask_nonlinear=cfg["mask_nonlinear"], causal=cfg["causal"], n_sources=cfg["n_sources"])
         FC.fill_model(model, synth)
-        mixture, sources = synth.make_batch(2, cfg["n_sources"], FC.E2E_T, seed=321)
+        mixture, sources = FC.e2e_batch(synth, cfg)
         out = model(mixture)
         loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources)
         loss.backward()

@@ -246,3 +246,13 @@ class SinkPIT(nn.Module):
                                            coldness=self.coldness, iteration=self.iteration, batch_mean=batch_mean)
         pattern = torch.argmax(permutation_matrix, dim=2)
         return loss, pattern
+
+
+class ProbPIT(nn.Module):
+    """Placeholder, as in the reference (src/criterion/pit.py:215-225: the forward pass is empty there too)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, input, target, batch_mean=True):
+        pass

@@ -187,3 +187,26 @@ def test_variants_at_bench_length_vs_float64(S):
     lb, perm = PIT1d(crit("NegSDR"), S)(est.to(dev()), tgt.to(dev()), batch_mean=False)
     assert torch.equal(perm.cpu(), ref_perm)
     assert_close(lb, ref_lb, 1e-5, "PIT NegSDR")
+
+
+def test_orpit_recovers_the_one_from_unsorted_packed_targets():
+    """The scenario of the reference's own self-test (src/criterion/pit.py:268-295): integer-valued sources, the input
+    holds source 0 and the sum of the others, the target lists the sources in a scrambled order and the batch is packed
+    unsorted; ORPIT must name the position of source 0 in every target, with a perfect score."""
+    from speech_amd.criterion.pit import ORPIT, ProbPIT
+    from speech_amd.utils import synth
+    T = 256
+    orders = [[2, 1, 0], [0, 1], [0, 2, 1], [1, 0]]
+    inputs, targets = [], []
+    for b, order in enumerate(orders):
+        src = torch.floor(5 * synth.uniform((len(order), T), 90 + b, lo=0.0, hi=1.0))
+        inputs.append(torch.stack([src[0], src[1:].sum(dim=0)]))
+        targets.append(src[order])
+    est = torch.stack(inputs).to(dev())
+    packed = nn.utils.rnn.pack_sequence([t_.to(dev()) for t_ in targets], enforce_sorted=False)
+    loss_b, idx = ORPIT(crit("SISDR"))(est, packed, batch_mean=False)
+    assert idx.cpu().tolist() == [order.index(0) for order in orders]
+    assert (loss_b > 100).all()                   # exact reconstruction: SI-SDR limited only by eps
+    loss_b, idx = ORPIT(crit("NegSDR"))(est, packed, batch_mean=False)
+    assert idx.cpu().tolist() == [order.index(0) for order in orders]
+    assert ProbPIT()(est, est) is None            # empty in the reference as well

@@ -78,7 +78,7 @@ class ConvTasNet(nn.Module):
 
     # ------------------------------------------------------------------ fused path
     def _fused_ok(self):
-        return (self.enc_basis == 'trainable' and self.dec_basis == 'trainable' and self.in_channels == 1
+        return (self.enc_basis == 'trainable' and self.dec_basis in ('trainable', 'pinv') and self.in_channels == 1
                 and self.dilated and self.separable and self.sep_nonlinear == 'prelu' and self.sep_norm
                 and self.mask_nonlinear == 'sigmoid' and self.kernel_size <= 16 and self.n_sources <= 3)
 
@@ -93,7 +93,10 @@ class ConvTasNet(nn.Module):
         g0, be0 = _norm_params(sep.norm1d)
         ps = [self.encoder.conv1d.weight, g0, be0, sep.bottleneck_conv1d.weight, sep.bottleneck_conv1d.bias]
         ps += sep.layer_parameters()
-        ps += [sep.prelu.weight, sep.mask_conv1d.weight, sep.mask_conv1d.bias, self.decoder.conv_transpose1d.weight]
+        # a pseudo-inverse decoder hands the fused schedule its derived basis; autograd carries the gradient on to the
+        # encoder weight through torch.pinverse
+        dec_W = self.decoder.get_basis() if self.dec_basis == 'pinv' else self.decoder.conv_transpose1d.weight
+        ps += [sep.prelu.weight, sep.mask_conv1d.weight, sep.mask_conv1d.bias, dec_W]
         return ps
 
     def forward(self, input):

@@ -66,8 +66,9 @@ class FlatTrainer:
         self.use_graph = bool(use_graph)
         self._graphs = {}
         self._eager_steps = 0
-        if not model._fused_ok():
-            raise NotImplementedError("FlatTrainer drives the fused Conv-TasNet schedule only")
+        if not model._fused_ok() or model.dec_basis != 'trainable':
+            raise NotImplementedError("FlatTrainer drives the fused Conv-TasNet schedule with a trainable encoder / "
+                                      "decoder pair only")
         params = model.fused_parameters()
         others = set(id(p) for p in model.parameters()) - set(id(p) for p in params)
         if others:

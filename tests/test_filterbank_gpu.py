@@ -148,5 +148,9 @@ def test_conv_tasnet_with_filterbank_variants(golden, key):
             assert_grad_close(grads[name].grad, g[k], "grad " + name)
             n += 1
     assert n > 20
+    # forward() may take the fused schedule, extract_latent() always goes module by module: same answer
+    out2, latent = model.extract_latent(mixture.to(dev()))
+    assert_close(out2, out.detach(), 1e-5, "fused vs modular")
+    assert latent.shape[:3] == (2, cfg["n_sources"], cfg["n_basis"])
     cfg_out = model.get_config()
     assert cfg_out["enc_basis"] == cfg["enc_basis"] and cfg_out["dec_basis"] == cfg["dec_basis"]

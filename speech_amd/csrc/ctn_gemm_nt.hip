@@ -481,14 +481,32 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
                 ntbf16x8 bh[TTN], bm[TTN], bl[TTN];
 #pragma unroll
                 for (int j = 0; j < TTN; ++j) {
+#ifdef CTN_DBG_NT_NO_SPLIT      // timing only: the raw bits stand in for the pieces
+                    union { float f[8]; ntbf16x8 v[2]; } u;
+                    for (int q = 0; q < 8; ++q) u.f[q] = b8[j][q];
+                    bh[j] = u.v[0], bl[j] = u.v[1], bm[j] = u.v[0];
+#else
                     if (SPLIT == 3) nt_split_bf16_3(b8[j], bh[j], bm[j], bl[j]);
                     else nt_split_bf16(b8[j], bh[j], bl[j]);
+#endif
                 }
 #pragma unroll
                 for (int i = 0; i < TTM; ++i) {
                     ntbf16x8 ah, am, al;
+#ifdef CTN_DBG_NT_NO_SPLIT
+                    union { float f[8]; ntbf16x8 v[2]; } u;
+                    for (int q = 0; q < 8; ++q) u.f[q] = a8[i][q];
+                    ah = u.v[0], al = u.v[1], am = u.v[0];
+#else
                     if (SPLIT == 3) nt_split_bf16_3(a8[i], ah, am, al);
                     else nt_split_bf16(a8[i], ah, al);
+#endif
+#ifdef CTN_DBG_NT_NO_MFMA       // timing only: keep the pieces alive without the matrix instructions
+#pragma unroll
+                    for (int j = 0; j < TTN; ++j)
+                        asm volatile("" ::"v"(ah), "v"(al), "v"(am), "v"(bh[j]), "v"(bl[j]), "v"(bm[j]));
+                    continue;
+#endif
                     // smallest products first; the tiles alternate so that consecutive instructions are independent
 #define CTN_NT_MFMA(a_, b_)                                                                                             \
     _Pragma("unroll") for (int j = 0; j < TTN; ++j)                                                                     \

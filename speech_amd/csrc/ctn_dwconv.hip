@@ -221,17 +221,26 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
 
     float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
     const int t = t0 + 4 * tid;                       // this thread's output frames
+    // which staged float4s are this thread's does not depend on the channel group, and neither do the per-frame
+    // statistics (they belong to the frames): fetched once, as whole float4s of the aligned statistics rows
+    int rr[NITC], ii[NITC];
+    f32x4 mu4[NITC], rs4[NITC];
+#pragma unroll
+    for (int j = 0; j < NITC; ++j) {
+        const int idx = tid + j * NTH;
+        const int r = idx / lw4, i4 = idx - r * lw4;
+        rr[j] = r, ii[j] = i4;
+        const int tt = min(max(tA + 4 * i4, 0), tl4);
+        mu4[j] = norm ? ctn_ld4(mrow + tt) : f32x4{0.f, 0.f, 0.f, 0.f};
+        rs4[j] = norm ? ctn_ld4(rrow + tt) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
     for (int cg = c0; cg < cend; cg += CS) {
         // ---- stage CS transformed, zero-padded rows; every load is issued before any is used
         f32x4 v[NITC];
-        int rr[NITC], ii[NITC];
 #pragma unroll
         for (int j = 0; j < NITC; ++j) {
-            const int idx = tid + j * NTH;
-            const int r = idx / lw4, i4 = idx - r * lw4;
-            rr[j] = r, ii[j] = i4;
-            const int c = min(cg + r, cend - 1);
-            const int tt = min(max(tA + 4 * i4, 0), tl4);
+            const int c = min(cg + rr[j], cend - 1);
+            const int tt = min(max(tA + 4 * ii[j], 0), tl4);
             v[j] = CTN_DW_LD(a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx + tt);
         }
 #pragma unroll
@@ -243,18 +252,13 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
             const int tt = tA + 4 * i4;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             if (c < cend && tt >= 0 && tt < T) {
-                float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
                 float g = 1.f, be = 0.f;
-                if (norm) {
-                    stat4(mrow, 0, a.sst, 0, tt, T, mrow[0], mu);
-                    stat4(rrow, 0, a.sst, 0, tt, T, rrow[0], rs);
-                    g = a.gamma[c], be = a.beta[c];
-                }
+                if (norm) g = a.gamma[c], be = a.beta[c];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float u = v[j][e];
                     if (prelu_in) u = ctn_prelu(u, ain);
-                    if (norm) u = (u - mu[e]) * rs[e] * g + be;
+                    if (norm) u = (u - mu4[j][e]) * rs4[j][e] * g + be;
                     o[e] = (tt + e < T) ? u : 0.f;
                 }
             }
@@ -802,7 +806,11 @@ int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream) {
     pick_tile(a.T, (a.P - 1) * a.dilation, a.cln != 0, 1, &CG, &TT, &lw);
     CTN_REQUIRE((size_t)lw * 4 <= 64 * 1024, "ctn_dw_fwd: dilation halo too large for LDS");
     constexpr int CS = 4;                               // rows staged at once by the cLN kernel
-    if (a.cln && stats && (a.P - 1) * a.dilation <= 500 && (!(a.xflags & CTN_XF_NORM) || a.sst == 1)) {
+    // statistics rows are read as float4s: unit stride, 16-byte aligned rows whose pitch covers T rounded up to 4
+    const bool stat_rows_ok = !(a.xflags & CTN_XF_NORM) ||
+                              (a.sst == 1 && ctn_aligned16(a.mean) && ctn_aligned16(a.rstd) && a.ssb % 4 == 0 &&
+                               a.ssb >= ((a.T + 3) & ~3));
+    if (a.cln && stats && (a.P - 1) * a.dilation <= 500 && stat_rows_ok) {
         CG = 16;
         dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
         const size_t shm = std::max((size_t)CS * lw, (size_t)8 * NTH) * 4;   // rows, or the per-frame sums on the way out

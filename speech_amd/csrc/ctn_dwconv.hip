@@ -488,6 +488,28 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
     }
 }
 
+// Sums NP (a power of two <= 32) per-lane values over a wave with NP - 1 + log2(64 / NP) exchanges instead of 6 * NP: at
+// every step a lane keeps one half of its values and hands the other half to its partner, so the values are spread
+// over the lanes while they are summed.  Returns, in every lane l, the wave total of value l % NP.
+template <int NP>
+__device__ __forceinline__ float wave_sum_scatter(float (&v)[NP]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int step = NP / 2; step >= 1; step >>= 1) {
+        const bool upper = (lane & step) != 0;
+#pragma unroll
+        for (int i = 0; i < step; ++i) {
+            const float send = upper ? v[i] : v[i + step];
+            const float keep = upper ? v[i + step] : v[i];
+            v[i] = keep + __shfl_xor(send, step);
+        }
+    }
+    float t = v[0];
+#pragma unroll
+    for (int m = NP; m < 64; m <<= 1) t += __shfl_xor(t, m);
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------ backward, cLN tiles
 // Cumulative norm on both sides: per-frame statistics, so a block walks CG channels of one time tile (TT <= 4 * NTH
 // frames) and keeps the per-frame sums of the norm-1 backward in registers.  What the general kernel above does per
@@ -501,7 +523,10 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [CS][D | Xh][lw]
     constexpr int CS = 2, NITB = 2;                    // host guarantees lw / 4 <= NITB * NTH
     constexpr int NV = 5 + P;
-    __shared__ float red[CS * NV * (NTH / 64)];
+    constexpr int NP = CS * NV <= 16 ? 16 : 32;        // per-phase values padded to a power of two
+    constexpr int MAXPH = 8;                           // phases per block: the host launches with CG <= CS * MAXPH
+    __shared__ float red[NTH / 64];
+    __shared__ float chan[MAXPH * NP];                 // per-channel sums of the block, added to by every wave
     const int b = blockIdx.z, c0 = blockIdx.y * CG, t0 = blockIdx.x * TT;
     const int T = a.T, d = a.dilation, padL = a.pad_left;
     const int tA = floor4(t0 - H);
@@ -530,6 +555,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
     float dalpha2 = 0.f;
     float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
     const int t = t0 + 4 * tid;                        // this thread's output frames (one float4 per channel)
+    if (tid < MAXPH * NP) chan[tid] = 0.f;             // visible after the first barrier of the loop
 
     for (int cg = c0; cg < cend; cg += CS) {
         f32x4 vdn[CS][NITB], vx[CS][NITB], vy[CS][NITB];
@@ -543,9 +569,9 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
                 vx[r][j] = CTN_DW_LD(a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx + ts[j]);
             }
         }
-        float v[CS * NV];
+        float v[NP];
 #pragma unroll
-        for (int i = 0; i < CS * NV; ++i) v[i] = 0.f;
+        for (int i = 0; i < NP; ++i) v[i] = 0.f;
 #pragma unroll
         for (int r = 0; r < CS; ++r) {
             const bool ch_ok = cg + r < cend;
@@ -624,18 +650,22 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
                 CTN_DW_ST(a.dx + (int64_t)b * a.dxbs + (int64_t)c * a.lddx + t, o);
             }
         }
-        // ---- per-channel reductions of both channels at once (its barriers also protect the LDS rows)
-        const float tot = ctn_block_sum<CS * NV>(v, red);
-        if (tid < CS * NV) {
-            const int r = tid / NV, q = tid - r * NV, c = cg + r;
-            if (c < cend) {
-                if (q == 0 && a.dgamma2) atomicAdd(a.dgamma2 + c, tot);
-                if (q == 1 && a.dbeta2) atomicAdd(a.dbeta2 + c, tot);
-                if (q == 2 && a.dbias) atomicAdd(a.dbias + c, tot);
-                if (q == 3 && a.dgamma1) atomicAdd(a.dgamma1 + c, tot);
-                if (q == 4 && a.dbeta1) atomicAdd(a.dbeta1 + c, tot);
-                if (q >= 5) atomicAdd(a.dw + (int64_t)c * P + (q - 5), tot);
-            }
+        // ---- per-channel reductions of both channels at once: summed over the wave, then into the block's LDS table
+        const float tot = wave_sum_scatter<NP>(v);
+        if ((tid & 63) < NP) atomicAdd(&chan[((cg - c0) / CS) * NP + (tid & 63)], tot);
+        __syncthreads();                               // the LDS rows are free for the next phase
+    }
+    if (tid < MAXPH * NP) {                            // one global atomic per channel and quantity
+        const int ph = tid / NP, i = tid - ph * NP;
+        const int r = i / NV, q = i - r * NV, c = c0 + ph * CS + r;
+        if (i < CS * NV && c < cend) {
+            const float tot = chan[tid];
+            if (q == 0 && a.dgamma2) atomicAdd(a.dgamma2 + c, tot);
+            if (q == 1 && a.dbeta2) atomicAdd(a.dbeta2 + c, tot);
+            if (q == 2 && a.dbias) atomicAdd(a.dbias + c, tot);
+            if (q == 3 && a.dgamma1) atomicAdd(a.dgamma1 + c, tot);
+            if (q == 4 && a.dbeta1) atomicAdd(a.dbeta1 + c, tot);
+            if (q >= 5) atomicAdd(a.dw + (int64_t)c * P + (q - 5), tot);
         }
     }
     {

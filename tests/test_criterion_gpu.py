@@ -210,3 +210,26 @@ def test_orpit_recovers_the_one_from_unsorted_packed_targets():
     loss_b, idx = ORPIT(crit("NegSDR"))(est, packed, batch_mean=False)
     assert idx.cpu().tolist() == [order.index(0) for order in orders]
     assert ProbPIT()(est, est) is None            # empty in the reference as well
+
+
+def test_pair_matrix_shape_sweep_vs_float64():
+    """The pairwise SI-SDR / SDR matrix and its full derivative over 1-4 sources and signal lengths from one sample to
+    beyond a block's chunk (two samples at least: one sample is always a perfect scaled match), against float64 on the CPU (values 1e-5, gradients 1e-4)."""
+    from speech_amd import ops
+    from speech_amd.criterion.sdr import PairFn
+    from speech_amd.utils import synth
+    for n, (B, S, T) in enumerate([(1, 1, 2), (2, 2, 3), (1, 3, 255), (3, 4, 4097), (2, 2, 9000), (5, 1, 513)]):
+        tgt = synth.normal((B, S, T), 800 + n, std=0.1)
+        est = 0.5 * tgt.flip(1) + synth.normal((B, S, T), 820 + n, std=0.05)
+        G = synth.normal((B, S, S), 840 + n)
+        for kind, fn in ((ops.PAIR_SISDR, CO.sisdr), (ops.PAIR_SDR, CO.sdr)):
+            e64 = est.double().requires_grad_(True)
+            ref = torch.stack([torch.stack([fn(e64[:, i], tgt[:, j].double()) for j in range(S)], dim=1)
+                               for i in range(S)], dim=1)
+            (ref * G.double()).sum().backward()
+            e = est.to(dev()).requires_grad_(True)
+            pair = PairFn.apply(e, tgt.to(dev()), 1e-12, kind)
+            (pair * G.to(dev())).sum().backward()
+            what = "kind {} shape {}".format(kind, (B, S, T))
+            assert_close(pair, ref, 1e-5, what)
+            assert_close(e.grad, e64.grad, 1e-4, what + " grad")

@@ -65,3 +65,35 @@ def test_kernel_longer_than_input_raises():
     m = DepthwiseSeparableConv1d(4, 4, 9, stride=2).to("cuda:0")
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 4, 5, device="cuda:0"))
+
+
+@pytest.mark.gpu
+def test_generic_depthwise_shape_sweep_vs_float64():
+    """Strided / dilated / padded depthwise convolutions over odd sizes (frame counts off the 4-float grid, kernels longer
+    than the stride and shorter, padding beyond the kernel, one frame of output), forward and backward through the C ABI,
+    against float64 conv1d on the CPU."""
+    import torch.nn.functional as F
+    from speech_amd.functional import DepthwiseGenericFn
+    dev = torch.device("cuda:0")
+    cases = [(1, 1, 1, 1, 1, 1, 0), (2, 3, 5, 7, 2, 1, 2), (3, 5, 37, 3, 2, 1, 1), (1, 7, 129, 4, 4, 3, 5), (2, 4, 1001, 16, 8, 1, 0),
+             (1, 2, 50, 3, 5, 2, 2), (2, 6, 257, 9, 1, 7, 28), (1, 3, 64, 2, 3, 1, 9), (1, 130, 33, 5, 2, 2, 4)]
+    for n, (B, C, T, K, stride, dil, pad) in enumerate(cases):
+        x = synth.normal((B, C, T), 700 + n, std=0.7)
+        w = synth.uniform((C, 1, K), 720 + n)
+        bias = synth.uniform((C,), 740 + n) if n % 2 == 0 else None
+        x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        b64 = None if bias is None else bias.double().requires_grad_(True)
+        y64 = F.conv1d(x64, w64, b64, stride=stride, padding=pad, dilation=dil, groups=C)
+        probe = synth.normal(tuple(y64.shape), 760 + n)
+        (y64 * probe.double()).sum().backward()
+        xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        bg = None if bias is None else bias.to(dev).requires_grad_(True)
+        y = DepthwiseGenericFn.apply(xg, wg, bg, stride, dil, pad)
+        (y * probe.to(dev)).sum().backward()
+        what = "case {}".format((B, C, T, K, stride, dil, pad))
+        assert tuple(y.shape) == tuple(y64.shape), what
+        assert_close(y, y64, 1e-5, what)
+        assert_close(xg.grad, x64.grad, 1e-5, what + " dx")
+        assert_close(wg.grad, w64.grad, 2e-5, what + " dw")
+        if bias is not None:
+            assert_close(bg.grad, b64.grad, 2e-5, what + " db")

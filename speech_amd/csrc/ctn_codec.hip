@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NTH) void maskdecode_bwd_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------ encoder bwd
 template <int ML, bool HAS_DWA, bool HAS_DN>
-__global__ __launch_bounds__(NTH) void encoder_bwd_kernel(const float* __restrict__ x, int64_t xbs, int Tin,
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 4))) void encoder_bwd_kernel(const float* __restrict__ x, int64_t xbs, int Tin,
                                                           int pad_left, int N, int L, int S, int relu,
                                                           const float* __restrict__ w, int Tf, int64_t ldw,
                                                           const float* __restrict__ dw_a, int64_t lddwa,

@@ -13,7 +13,9 @@ The line also carries
                 instrumented step: algorithmic FLOPs of its launches / their summed duration, vs the 157.3
                 TFLOP/s dense f32 matrix peak of MI355X;
   roofline_hbm  the same for the fused depthwise kernels against the 8 TB/s HBM3E peak
-                (algorithmic bytes: forward 2 x H x T' x 4, backward 4 x H x T' x 4 per utterance and layer);
+                (algorithmic bytes: forward 2 x H x T' x 4, backward 3 x H x T' x 4 per utterance and layer; the
+                backward kernel moves a fourth tensor, reported beside it), with the rate of a hand-written 16-byte
+                copy kernel and of the bare f32-MFMA loop measured in the same process as yardsticks;
   cpu_baseline  the CPU oracle (a PyTorch restatement of the reference's step) timed on this host.
 """
 import argparse
@@ -69,7 +71,9 @@ def instrumented_step(trainer, mixture, sources):
     ops.gemm_nn = wrap("gemm_nn", lambda M, T, K, batch, *a, **k: 2.0 * M * T * K * batch)
     ops.gemm_nt = wrap("gemm_nt", lambda M, N, T, batch, *a, **k: 2.0 * M * N * T * batch)
     ops.dw_fwd = wrap("dw_fwd", lambda x, w, bias, y, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
-    ops.dw_bwd = wrap("dw_bwd", lambda dn2, x, *a, **k: 4.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
+    # the contract prices the backward kernel at 3 tensors (read x, read dy, write dx); the kernel also reads the saved
+    # convolution output instead of recomputing it, 4 tensors moved -- both fractions are reported
+    ops.dw_bwd = wrap("dw_bwd", lambda dn2, x, *a, **k: 3.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
     # per-kernel timing needs eager launches on ONE stream (two sub-batch streams overlap kernels, which makes a
     # kernel's own duration meaningless); the work is the same full per-GPU batch
     graph_mode, trainer.use_graph = trainer.use_graph, False
@@ -112,21 +116,56 @@ def profiled_traffic(prefix, batch):
     return round(tot / n) if n else None
 
 
-def device_copy_rate(device, mbytes=1024, reps=10):
-    """GB/s (read + write) of a plain device-to-device copy of a buffer larger than the last-level cache: what a
-    streaming kernel reaches on this GPU, reported beside the nominal HBM peak."""
+def _probe_rate(device, two_reads, mbytes=1024, reps=10):
+    """GB/s of the library's own streaming probe (16-byte non-temporal loads and stores, nothing else) on buffers larger
+    than the last-level cache: copy (one read, one write) or two reads and one write."""
+    from speech_amd import _lib
+    lib = _lib.load()
     n = mbytes * 1024 * 1024 // 4
-    x = torch.empty(n, device=device, dtype=torch.float32).normal_()
-    y = torch.empty_like(x)
+    a = torch.empty(n, device=device, dtype=torch.float32).normal_()
+    b = torch.empty_like(a).normal_() if two_reads else None
+    y = torch.empty_like(a)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        _lib.check(lib.ctn_probe_copy(a.data_ptr(), b.data_ptr() if two_reads else None, y.data_ptr(), n, stream),
+                   "ctn_probe_copy")
     for _ in range(3):
-        y.copy_(x)
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        y.copy_(x)
+        run()
     e1.record()
     torch.cuda.synchronize()
-    return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return (3.0 if two_reads else 2.0) * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def device_copy_rate(device):
+    return _probe_rate(device, False)
+
+
+def device_2r1w_rate(device):
+    return _probe_rate(device, True)
+
+
+def mfma_bare_loop_rate(device, iters=20000):
+    """TFLOP/s of v_mfma_f32_32x32x2_f32 issued back to back from registers on random operands by every SIMD of the
+    chip (four waves per SIMD, four independent accumulators per wave): the f32 matrix rate this GPU sustains with no
+    memory, LDS or vector work in the way."""
+    from speech_amd import _lib
+    lib = _lib.load()
+    blocks = 256 * 4
+    src = torch.empty(65536, device=device, dtype=torch.float32).normal_()
+    out = torch.empty(blocks * 256, device=device, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ctn_probe_mfma_f32(src.data_ptr(), out.data_ptr(), blocks, 200, stream), "ctn_probe_mfma_f32")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(lib.ctn_probe_mfma_f32(src.data_ptr(), out.data_ptr(), blocks, iters, stream), "ctn_probe_mfma_f32")
+    e1.record()
+    torch.cuda.synchronize()
+    return blocks * 4.0 * iters * 4 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
 def plain_gemm_rate(device, constant, batch=16, reps=30):
@@ -160,8 +199,17 @@ def cpu_baseline(cfg, steps=24, warmup=2, batch=2):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import convtasnet_oracle as O
     from speech_amd.utils import synth
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
+    # threads: the share of the host this job may use (OMP_NUM_THREADS on a shared GPU box, else every core)
+    cores = torch.get_num_threads()
+    model_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model_name = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     sd = synth.fill_parameters(O.make_state(cfg), salt=1)
     opt = O.AdamState(sd)
     times = []
@@ -171,7 +219,8 @@ def cpu_baseline(cfg, steps=24, warmup=2, batch=2):
         O.train_step(mixture, sources, sd, cfg, opt)
         times.append(time.perf_counter() - t0)
     dt = sum(times[warmup:]) / steps
-    return dict(value=round(batch / dt, 3), unit="utt/s", cores=cores, kind="port",
+    return dict(value=round(batch / dt, 3), unit="utt/s", cores=cores, host_cpu_count=os.cpu_count(),
+                cpu_model=model_name, kind="port",
                 sample="{} training steps of batch {} (paper config, 4 s @ 8 kHz) after {} warm-up, "
                        "PyTorch CPU restatement of the reference step".format(steps, batch, warmup))
 
@@ -189,6 +238,8 @@ def main():
     ap.add_argument("--no-split-probe", action="store_true",
                     help="skip the second, informational measurement with split-bf16 GEMM products")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-recipe-batch", action="store_true",
+                    help="skip the informational measurement at the reference recipe's batch of 2 per GPU")
     args = ap.parse_args()
 
     if os.environ.get("CTN_BENCH_TRACE_AFTER"):      # debugging aid: dump every thread's stack and exit after N seconds
@@ -291,6 +342,31 @@ def main():
             trainer._graphs.clear()
             trainer._eager_steps = 0
 
+    # The reference recipe's own per-GPU batch (egs/wsj0-mix/conv-tasnet/train.sh:54: batch_size=2), same step, same
+    # mode: informational, never `value`.
+    recipe = None
+    if world == 1 and not args.no_recipe_batch and args.batch != 2:
+        small = []
+        for i in range(n_batches):
+            mixture, sources = synth.make_batch(2, cfg["n_sources"], T_SAMPLES, seed=5000 + i)
+            small.append((mixture.to(device), sources.to(device)))
+        keep_streams, trainer.n_streams = trainer.n_streams, 1      # two utterances are one sub-batch
+        n_small = max(args.steps, 50)
+        try:
+            for i in range(3 + args.warmup):
+                trainer.step(*small[i % n_batches])
+            barrier()
+            t2 = time.perf_counter()
+            for i in range(n_small):
+                trainer.step(*small[i % n_batches])
+            barrier()
+            dt2 = time.perf_counter() - t2
+        finally:
+            trainer.n_streams = keep_streams
+        recipe = dict(value=round(2 * n_small / dt2, 3), unit="utt/s", per_gpu_batch=2, steps=n_small,
+                      ms_per_step=round(dt2 / n_small * 1e3, 3),
+                      note="the reference recipe's batch size per GPU; a step is ~570 launches that no longer fill the chip")
+
     roof = roof_hbm = None
     extra = {}
     prof = None
@@ -308,6 +384,7 @@ def main():
                     mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph is the profiled command)",
                     launches_per_step=gn["launches"],
                     avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1),
+                    mfma_bare_loop=round(mfma_bare_loop_rate(device), 1),
                     plain_gemm_on_random_operands=round(plain_gemm_rate(device, False), 1),
                     plain_gemm_on_constant_operands=round(plain_gemm_rate(device, True), 1))
         b = gt["work"] / (gt["ms"] * 1e-3) / 1e12
@@ -316,15 +393,24 @@ def main():
                                        frac=round(b / PEAK_F32_MFMA_TFLOPS, 4), launches_per_step=gt["launches"],
                                        avg_launch_us=round(gt["ms"] * 1e3 / gt["launches"], 1))
         copy_gbs = device_copy_rate(device)
+        rw2_gbs = device_2r1w_rate(device)
         hb = []
         for name in ("dw_fwd", "dw_bwd"):
             d = prof[name]
             gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
-            hb.append(dict(bound="hbm", kernel=name + "_kernel", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
-                           unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
-                           traffic=profiled_traffic(name, args.batch),
-                           launches_per_step=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 1),
-                           device_copy_rate=round(copy_gbs, 1), frac_of_copy_rate=round(gbs / copy_gbs, 4)))
+            row = dict(bound="hbm", kernel=name + "_kernel", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
+                       unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                       traffic=profiled_traffic(name, args.batch),
+                       launches_per_step=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 1),
+                       bytes_priced="2 x H x T' x 4 per utterance (read y1, write y2)" if name == "dw_fwd" else
+                                    "3 x H x T' x 4 per utterance (read x, read dy, write dx)",
+                       copy_kernel_rate=round(copy_gbs, 1), two_read_one_write_kernel_rate=round(rw2_gbs, 1),
+                       frac_of_copy_kernel=round(gbs / copy_gbs, 4))
+            if name == "dw_bwd":      # what the kernel moves: it reads the saved convolution output as a fourth tensor
+                moved = gbs * 4.0 / 3.0
+                row["moved_bytes"] = dict(achieved=round(moved, 1), frac=round(moved / PEAK_HBM_GBS, 4),
+                                          frac_of_two_read_one_write_kernel=round(moved / rw2_gbs, 4))
+            hb.append(row)
         roof_hbm = hb
         step_ms = dt / args.steps * 1e3
         extra["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof.items()}
@@ -356,6 +442,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp{}".format(world), "sub_batch_streams": args.streams,
                        "hip_graph": bool(args.graph), "final_loss": round(final_loss, 4)},
+            "recipe_batch_2": recipe,
             "split_bf16_mode": split_probe,
             "roofline": roof,
             "roofline_hbm": roof_hbm,

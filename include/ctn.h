@@ -88,6 +88,15 @@ int ctn_gemm_nn_set_tile(int width);
 int ctn_gemm_set_split(int pieces);
 int ctn_gemm_get_split(void);
 
+/* Measurement aids without a counterpart in the reference: the rates the GPU itself sustains, for the benchmark to
+ * report beside the kernels' own.
+ * ctn_probe_copy: y = a (b NULL) or y = a + b, n floats (n % 4 == 0, 16-byte aligned), non-temporal 16-byte accesses;
+ *   moves 8n (copy) or 12n (two reads, one write) bytes.
+ * ctn_probe_mfma_f32: `blocks` blocks of four waves each issue iters x 4 v_mfma_f32_32x32x2_f32 back to back on operands
+ *   held in registers (read once from in[0..65535]); out receives blocks*256 floats.  FLOPs = blocks*4*iters*4*4096. */
+int ctn_probe_copy(const float* a, const float* b, float* y, int64_t n, void* stream);
+int ctn_probe_mfma_f32(const float* in, float* out, int blocks, int iters, void* stream);
+
 /* dst[k * ldd + coff + m] = src[m * K + k]  (m < M, k < K).  Lays a Conv1d(kernel_size=1) weight
  * (M_out, K_in) out k-major for ctn_gemm_nn. */
 int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64_t coff, void* stream);

@@ -39,14 +39,20 @@ class _PitSISDRFn(torch.autograd.Function):
         return dest, None, None
 
 
-def _fusable(criterion, input):
+def _same_signals(input, target):
+    """The kernels walk the target with the estimate's batch, source and sample counts, so both must agree; anything
+    else (the reference's generic loop allows a different number of target sources) takes the generic route."""
+    return torch.is_tensor(target) and target.shape == input.shape and target.device == input.device
+
+
+def _fusable(criterion, input, target):
     return (isinstance(criterion, (NegSISDR, SISDR)) and criterion.reduction == 'mean' and input.dim() == 3
-            and input.size(1) <= 4 and input.is_cuda)
+            and input.size(1) <= 4 and input.is_cuda and _same_signals(input, target))
 
 
-def _pair_kind(criterion, input):
+def _pair_kind(criterion, input, target):
     """ops.PAIR_* when criterion(input_i, target_j) can be read off the pairwise matrix kernels, else None."""
-    if not (input.is_cuda and input.dim() == 3 and input.size(1) <= 4):
+    if not (input.is_cuda and input.dim() == 3 and input.size(1) <= 4 and _same_signals(input, target)):
         return None
     if type(criterion) in (NegSISDR, SISDR):
         return ops.PAIR_SISDR
@@ -79,7 +85,7 @@ def pit(criterion, input, target, n_sources=None, patterns=None, batch_mean=True
         patterns = torch.tensor(list(itertools.permutations(range(n_sources))), dtype=torch.long)
     maximize = hasattr(criterion, "maximize") and criterion.maximize
 
-    if _fusable(criterion, input) and patterns.size(0) == _factorial(input.size(1)):
+    if _fusable(criterion, input, target) and patterns.size(0) == _factorial(input.size(1)):
         loss, perm = _PitSISDRFn.apply(input, target, criterion.eps)
         if maximize:    # SISDR: max over permutations of +mean = -(min of -mean), same winner and tie rule
             loss = -loss
@@ -87,7 +93,7 @@ def pit(criterion, input, target, n_sources=None, patterns=None, batch_mean=True
             loss = loss.mean(dim=0)
         return loss, perm
 
-    kind = _pair_kind(criterion, input)
+    kind = _pair_kind(criterion, input, target)
     if kind is not None and criterion.reduction in ('mean', 'sum') and input.size(1) == target.size(1) == patterns.size(1):
         S = input.size(1)
         pair = PairFn.apply(input, target, criterion.eps, kind)                     # (B, S, S)
@@ -205,7 +211,7 @@ def sinkpit(criterion, input, target, n_sources=None, coldness=1e+0, iteration=1
         n_sources = input.size(1)
     batch_size = input.size(0)
     maximize = hasattr(criterion, "maximize") and criterion.maximize
-    kind = _pair_kind(criterion, input)
+    kind = _pair_kind(criterion, input, target)
     if kind is not None and input.size(1) == target.size(1) == n_sources:
         # criterion on 2-D inputs has no reduction over sources (sdr.py:49-59): the matrix entries themselves
         possible_loss = criterion.sign * PairFn.apply(input, target, criterion.eps, kind)

@@ -1,0 +1,87 @@
+// Measurement aids: what the chip itself sustains, measured with the simplest kernels that can reach it, so that the
+// roofline fractions reported for the real kernels have a yardstick taken on the same GPU in the same process.
+//   copy / 2-read-1-write : 16-byte non-temporal loads and stores, grid-stride, nothing else
+//   bare MFMA loop        : v_mfma_f32_32x32x2_f32 back to back on four independent accumulators per wave, operands in
+//                           registers (loaded once from random data), no LDS or memory traffic inside the loop
+#include "ctn_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(const f32x4* __restrict__ a, f32x4* __restrict__ y, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // four independent 16-byte loads in flight per thread before the first store
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f32x4 v0 = __builtin_nontemporal_load(a + i);
+        const f32x4 v1 = __builtin_nontemporal_load(a + i + stride);
+        const f32x4 v2 = __builtin_nontemporal_load(a + i + 2 * stride);
+        const f32x4 v3 = __builtin_nontemporal_load(a + i + 3 * stride);
+        __builtin_nontemporal_store(v0, y + i);
+        __builtin_nontemporal_store(v1, y + i + stride);
+        __builtin_nontemporal_store(v2, y + i + 2 * stride);
+        __builtin_nontemporal_store(v3, y + i + 3 * stride);
+    }
+    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), y + i);
+}
+
+__global__ __launch_bounds__(256) void probe_2r1w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                                         f32x4* __restrict__ y, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const f32x4 a0 = __builtin_nontemporal_load(a + i), b0 = __builtin_nontemporal_load(b + i);
+        const f32x4 a1 = __builtin_nontemporal_load(a + i + stride), b1 = __builtin_nontemporal_load(b + i + stride);
+        __builtin_nontemporal_store(a0 + b0, y + i);
+        __builtin_nontemporal_store(a1 + b1, y + i + stride);
+    }
+    for (; i < n4; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(a + i) + __builtin_nontemporal_load(b + i), y + i);
+}
+
+__global__ __launch_bounds__(256) void probe_mfma_f32_kernel(const float* __restrict__ in, float* out, int iters) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    float a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = in[(tid * 8 + i) & 65535];
+        b[i] = in[(tid * 8 + 4 + i) & 65535];
+    }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c3, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    out[tid] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctn_probe_copy(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    CTN_REQUIRE(a && y && n > 0 && n % 4 == 0 && ctn_aligned16(a) && ctn_aligned16(y) && (!b || ctn_aligned16(b)),
+                "ctn_probe_copy: needs 16-byte aligned buffers and n %% 4 == 0");
+    const int blocks = 256 * 8;
+    if (b)
+        hipLaunchKernelGGL(probe_2r1w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a,
+                           (const f32x4*)b, (f32x4*)y, n / 4);
+    else
+        hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a, (f32x4*)y,
+                           n / 4);
+    CTN_CHECK_LAUNCH("ctn_probe_copy");
+    return CTN_OK;
+}
+
+int ctn_probe_mfma_f32(const float* in, float* out, int blocks, int iters, void* stream) {
+    CTN_REQUIRE(in && out && blocks > 0 && iters > 0, "ctn_probe_mfma_f32: bad arguments");
+    hipLaunchKernelGGL(probe_mfma_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, iters);
+    CTN_CHECK_LAUNCH("ctn_probe_mfma_f32");
+    return CTN_OK;
+}
+
+}  // extern "C"

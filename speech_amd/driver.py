@@ -6,7 +6,7 @@ recipe's `AdhocTrainer`, egs/wsj0-mix/conv-tasnet/src/adhoc_driver.py:7-44): sam
 side resumes on the other.  What differs is underneath: the optimizer step is the fused clip + Adam kernel of
 `FlatTrainer` on flat buffers, the `torch.optim.Adam` object the caller passes in supplies the hyper-parameters,
 carries the learning rate (the schedule halves `param_groups[...]['lr']` exactly as the reference does) and gives
-the checkpoint its `optim_dict` layout.  The loss plot (driver.py:120-121) is not drawn: no plotting dependency here.
+the checkpoint its `optim_dict` layout.
 """
 import os
 import time
@@ -107,6 +107,18 @@ def import_adam_state(optimizer, flat_trainer, optim_dict):
     flat_trainer.betas, flat_trainer.eps = tuple(g['betas']), g['eps']
 
 
+def allreduce_host_safe(t, group=None):
+    """Sum-all-reduce of a small device tensor in place; through a host copy when the process group is gloo (several
+    ranks rehearsing on one GPU), directly on RCCL otherwise."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 class TrainerBase:
     """egs/wsj0-mix/common/src/driver.py:20-226.  `args` needs: sample_rate, n_sources, max_norm, model_dir, loss_dir,
     sample_dir, epochs, use_cuda, continue_from, overwrite.  Extra keyword arguments go to FlatTrainer
@@ -202,6 +214,13 @@ class TrainerBase:
                         print("Learning rate: {} -> {}".format(prev_lr, lr))
                     param_group['lr'] = lr
             self.save_model(epoch, os.path.join(self.model_dir, "last.pth"))
+            if self.rank == 0:                # driver.py:120-121
+                try:
+                    from .utils.utils import draw_loss_curve
+                    draw_loss_curve(train_loss=self.train_loss[:epoch + 1], valid_loss=self.valid_loss[:epoch + 1],
+                                    save_path=os.path.join(self.loss_dir, "loss.png"))
+                except ImportError:           # no plotting library on this node: the numbers are in the checkpoint
+                    pass
 
     def run_one_epoch(self, epoch):
         train_loss = self.run_one_epoch_train(epoch)
@@ -226,28 +245,36 @@ class TrainerBase:
                 print("[Epoch {}/{}] iter {}/{} loss: {:.5f}".format(epoch + 1, self.epochs, idx + 1, n_train_batch,
                                                                      loss.item()), flush=True)
         if self.flat.world > 1:               # every rank saw an equal shard of every batch: mean of the shard means
-            dist.all_reduce(total, group=self.flat.group)
+            allreduce_host_safe(total, self.flat.group)
             total /= self.flat.world
         return total.item() / n_train_batch
 
     def run_one_epoch_eval(self, epoch):
-        """driver.py:166-206: PIT loss of every validation utterance (batch_mean=False), summed, over the dataset size."""
+        """driver.py:166-206: PIT loss of every validation utterance (batch_mean=False), summed, over the number of
+        utterances.  The reference divides by len(valid_loader.dataset), which in its single process is the number of
+        utterances the loop saw; here that number is counted, so that with several ranks -- each given its own part of
+        the set by a disjoint dataset or by a DistributedSampler over a shared one, padding duplicates included -- the
+        all-reduced sum is divided by what was actually evaluated."""
         self.model.eval()
         dev = self.flat.flat_p.device
         total = torch.zeros((), device=dev, dtype=torch.float64)
-        n_valid = len(self.valid_loader.dataset)
+        n_seen = 0
         with torch.no_grad():
             for idx, batch in enumerate(self.valid_loader):
                 mixture, sources = batch[0].to(dev), batch[1].to(dev)
                 output = self.model(mixture)
                 loss, _ = self.pit_criterion(output, sources, batch_mean=False)
                 total += loss.sum(dim=0).double()
+                n_seen += loss.numel()
                 if idx < 5 and self.rank == 0 and len(batch) > 2:
                     self.save_samples(epoch, batch[2][0], mixture[0].squeeze(dim=0).cpu(), output[0].cpu())
-        n = torch.tensor(float(n_valid), device=dev, dtype=torch.float64)
+        n = torch.tensor(float(n_seen), device=dev, dtype=torch.float64)
         if self.flat.world > 1:               # every rank validates its own part of the set
-            dist.all_reduce(total, group=self.flat.group)
-            dist.all_reduce(n, group=self.flat.group)
+            pair = torch.stack([total, n])
+            allreduce_host_safe(pair, self.flat.group)
+            total, n = pair[0], pair[1]
+        if n.item() == 0:
+            raise ValueError("the validation loader produced no utterances")
         return (total / n).item()
 
     def save_samples(self, epoch, segment_ID, mixture, estimated_sources):
@@ -277,6 +304,16 @@ class TrainerBase:
         config['valid_loss'] = self.valid_loss
         config['epoch'] = epoch + 1
         torch.save(config, model_path)
+
+
+class TesterBase:
+    """Placeholder for the reference's evaluation driver (egs/wsj0-mix/common/src/driver.py:228-390): it scores with
+    mir_eval's BSS metrics and an external PESQ executable, neither of which is part of the accelerated path.  The name
+    exists so that recipe modules importing it keep importing; constructing it says what is missing."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("evaluation (mir_eval BSS metrics, PESQ subprocess) is outside the MI355X training path; "
+                                  "run the reference's tester on a checkpoint written by this trainer instead")
 
 
 class AdhocTrainer(TrainerBase):

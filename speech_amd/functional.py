@@ -556,6 +556,9 @@ class ConvTasNetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("the fused Conv-TasNet schedule has no gradient with respect to the mixture; "
+                                      "use ConvTasNet.extract_latent (module by module) for that")
         mp = ctx.mp
         cfg = mp.cfg
         x2, w, mask, saved, pad_left, relu = ctx.saved_acts

@@ -100,7 +100,10 @@ class ConvTasNet(nn.Module):
         return ps
 
     def forward(self, input):
-        if input.dim() == 3 and self._fused_ok():
+        # the fused schedule does not produce the gradient of the mixture; a caller that differentiates with respect to
+        # the input waveform gets the module-by-module path, which does
+        wants_input_grad = torch.is_grad_enabled() and input.requires_grad
+        if input.dim() == 3 and self._fused_ok() and not wants_input_grad:
             batch_size, C_in, T = input.size()
             assert C_in == 1, "input.size() is expected (?, 1, ?), but given {}".format(input.size())
             return ConvTasNetFn.apply(input, self.fused_config(), *self.fused_parameters())

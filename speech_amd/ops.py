@@ -459,9 +459,21 @@ def maskdecode_bwd(dout, trim_left, w, mask, n_src, Wd, S, sigmoid_bwd, dz, dw_d
 
 
 # ------------------------------------------------------------------------------------------------ loss / optimizer
+def _check_signal_pair(est, tgt):
+    """The loss kernels index the target with the estimate's sizes and strides: refuse anything else here, before a
+    mismatched pair becomes a silent wrong loss or an out-of-bounds device read."""
+    _require_cuda(est, tgt)
+    if (est.dim() != 3 or tgt.shape != est.shape or tgt.stride() != est.stride() or est.stride(2) != 1
+            or est.dtype != torch.float32 or tgt.dtype != torch.float32 or tgt.device != est.device):
+        raise _lib.CtnError("loss kernels need estimate and target as fp32 (B, S, T) tensors of the same shape, strides "
+                            "and device with unit time stride; got {} {} and {} {}".format(
+                                tuple(est.shape), est.stride(), tuple(tgt.shape), tgt.stride()))
+
+
 def pit_sisdr_fwd(est, tgt, eps, fixed_perm=False):
     """est, tgt (B, S, T) unit time stride, same strides.  Returns pair, loss_b, perm (int64), coef."""
     lib = _lib.load()
+    _check_signal_pair(est, tgt)
     B, S, T = est.shape
     dev = est.device
     work = torch.zeros((B, 2 * S * S + S), device=dev, dtype=torch.float64)
@@ -478,6 +490,7 @@ def pit_sisdr_fwd(est, tgt, eps, fixed_perm=False):
 
 def pit_sisdr_bwd(est, tgt, perm, coef, gscale, gs_bstride, gs_istride):
     lib = _lib.load()
+    _check_signal_pair(est, tgt)
     B, S, T = est.shape
     dest = torch.empty((B, S, T), device=est.device, dtype=torch.float32)
     _lib.check(lib.ctn_pit_sisdr_bwd(_ptr(est), _ptr(tgt), B, S, T, est.stride(1), est.stride(0), _ptr(perm),
@@ -518,6 +531,7 @@ def pair_sdr_fwd(est, tgt, eps, kind):
     """est, tgt (B, S, T) contiguous, S <= 4.  Returns pair (B, S, S) = criterion(est_i, tgt_j) in dB (kind: PAIR_SISDR or
     PAIR_SDR) and paircoef (B, S, S, 2), the coefficients of d pair / d est_i = ct * tgt_j + ce * est_i."""
     lib = _lib.load()
+    _check_signal_pair(est, tgt)
     B, S, T = est.shape
     dev = est.device
     work = torch.zeros((B, 2 * S * S + S), device=dev, dtype=torch.float64)
@@ -531,6 +545,7 @@ def pair_sdr_fwd(est, tgt, eps, kind):
 def pair_sdr_bwd(est, tgt, A, Cc):
     """dest_i = sum_j A[b, i, j] tgt_j + Cc[b, i] est_i."""
     lib = _lib.load()
+    _check_signal_pair(est, tgt)
     B, S, T = est.shape
     dest = torch.empty((B, S, T), device=est.device, dtype=torch.float32)
     _lib.check(lib.ctn_pair_sdr_bwd(_ptr(est), _ptr(tgt), B, S, T, est.stride(1), est.stride(0), _ptr(A), _ptr(Cc),

@@ -65,6 +65,7 @@ class FlatTrainer:
         # (whose bias correction changes every step) stay outside the graph.
         self.use_graph = bool(use_graph)
         self._graphs = {}
+        self.max_graphs = 2
         self._eager_steps = 0
         if not model._fused_ok() or model.dec_basis != 'trainable':
             raise NotImplementedError("FlatTrainer drives the fused Conv-TasNet schedule with a trainable encoder / "
@@ -104,6 +105,10 @@ class FlatTrainer:
             return self._forward_backward(mixture, sources)
         key = (tuple(mixture.shape), tuple(sources.shape))
         entry = self._graphs.get(key)
+        if entry is None and len(self._graphs) >= self.max_graphs:
+            # every captured shape keeps its own pool of activations (several GB at batch 32): other shapes -- a ragged
+            # last batch, variable-length training -- run eagerly.  Use fixed-length batches (drop_last) with use_graph.
+            return self._forward_backward(mixture, sources)
         if entry is None:
             if self._eager_steps < 2:              # lazy initialisation (library load, caches) happens eagerly
                 self._eager_steps += 1

@@ -1,33 +1,33 @@
-"""Activation and RNN factories with the reference's interface (src/utils/model.py:3-32)."""
+"""String -> torch.nn module lookups behind the model constructors (same names, arguments and failures as
+src/utils/model.py:3-32 of the reference)."""
 import torch.nn as nn
+
+_ACTIVATIONS = {
+    'relu': nn.ReLU,
+    'sigmoid': nn.Sigmoid,
+    'softmax': nn.Softmax,
+    'tanh': nn.Tanh,
+    'leaky-relu': nn.LeakyReLU,
+    'gelu': nn.GELU,
+}
+_RECURRENT = {'rnn': nn.RNN, 'lstm': nn.LSTM, 'gru': nn.GRU}
 
 
 def choose_nonlinear(name, **kwargs):
-    if name == 'relu':
-        nonlinear = nn.ReLU()
-    elif name == 'sigmoid':
-        nonlinear = nn.Sigmoid()
-    elif name == 'softmax':
-        assert 'dim' in kwargs, "dim is expected for softmax."
-        nonlinear = nn.Softmax(**kwargs)
-    elif name == 'tanh':
-        nonlinear = nn.Tanh()
-    elif name == 'leaky-relu':
-        nonlinear = nn.LeakyReLU()
-    elif name == 'gelu':
-        nonlinear = nn.GELU()
-    else:
+    """Activation module for `name`.  Only softmax takes arguments (its `dim`, which must be given); for every other
+    name keyword arguments are ignored, as in the reference."""
+    factory = _ACTIVATIONS.get(name)
+    if factory is None:
         raise NotImplementedError("Invalid nonlinear function is specified. Choose 'relu' instead of {}.".format(name))
-    return nonlinear
+    if factory is nn.Softmax:
+        assert 'dim' in kwargs, "dim is expected for softmax."
+        return factory(**kwargs)
+    return factory()
 
 
 def choose_rnn(name, **kwargs):
-    if name == 'rnn':
-        rnn = nn.RNN(**kwargs)
-    elif name == 'lstm':
-        rnn = nn.LSTM(**kwargs)
-    elif name == 'gru':
-        rnn = nn.GRU(**kwargs)
-    else:
+    """nn.RNN / nn.LSTM / nn.GRU built with `kwargs`."""
+    factory = _RECURRENT.get(name)
+    if factory is None:
         raise NotImplementedError("Invalid RNN is specified. Choose 'rnn', 'lstm', or 'gru' instead of {}.".format(name))
-    return rnn
+    return factory(**kwargs)

@@ -1,26 +1,26 @@
-"""Norm factory with the reference's interface (src/utils/tasnet.py:14-32)."""
+"""Layer-norm lookup behind the TasNet constructors (interface of src/utils/tasnet.py:14-32 of the reference):
+'cLN' -> cumulative norm, 'gLN' -> global norm (refused for causal models), 'BN' / 'batch' / 'batch_norm' ->
+nn.BatchNorm1d or nn.BatchNorm2d by the `n_dims` keyword."""
 import torch.nn as nn
 
 from ..modules.norm import GlobalLayerNorm, CumulativeLayerNorm1d
 
 EPS = 1e-12
+_BATCH_NORM_NAMES = ('BN', 'batch', 'batch_norm')
+_BATCH_NORM_BY_DIMS = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d}
 
 
 def choose_layer_norm(name, num_features, causal=False, eps=EPS, **kwargs):
+    if name == 'gLN' and causal:
+        raise ValueError("Global Layer Normalization is NOT causal.")
+    if name == 'gLN':
+        return GlobalLayerNorm(num_features, eps=eps)
     if name == 'cLN':
-        layer_norm = CumulativeLayerNorm1d(num_features, eps=eps)
-    elif name == 'gLN':
-        if causal:
-            raise ValueError("Global Layer Normalization is NOT causal.")
-        layer_norm = GlobalLayerNorm(num_features, eps=eps)
-    elif name in ['BN', 'batch', 'batch_norm']:
+        return CumulativeLayerNorm1d(num_features, eps=eps)
+    if name in _BATCH_NORM_NAMES:
         n_dims = kwargs.get('n_dims') or 1
-        if n_dims == 1:
-            layer_norm = nn.BatchNorm1d(num_features, eps=eps)
-        elif n_dims == 2:
-            layer_norm = nn.BatchNorm2d(num_features, eps=eps)
-        else:
+        batch_norm = _BATCH_NORM_BY_DIMS.get(n_dims)
+        if batch_norm is None:
             raise NotImplementedError("n_dims is expected 1 or 2, but give {}.".format(n_dims))
-    else:
-        raise NotImplementedError("Not support {} layer normalization.".format(name))
-    return layer_norm
+        return batch_norm(num_features, eps=eps)
+    raise NotImplementedError("Not support {} layer normalization.".format(name))

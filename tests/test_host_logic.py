@@ -3,6 +3,7 @@
 real library validating all arguments (launches fail with 'no device' here, which the dry run tolerates)."""
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -230,3 +231,41 @@ def test_criterion_variants_surface_and_no_cpu_fallback():
     assert P_.argmax(dim=2).tolist() == [[1, 0], [1, 0]]
     loss, idx = P.ORPIT(mse)(torch.stack([t[:, 1], t[:, 0]], dim=1), t, batch_mean=False)
     assert idx.tolist() == [1, 1] and torch.allclose(loss, torch.zeros(2))
+
+
+def test_reference_import_names_resolve_through_compat_path():
+    """The recipes import top-level `models`, `criterion`, `utils`, `dataset`, `driver`, `adhoc_driver`, `norm`, `conv`
+    (egs/wsj0-mix/conv-tasnet/local/train.py:9-14, path.sh:4); with compat/ on PYTHONPATH in place of the reference's
+    src directories those statements must load this package's classes."""
+    import subprocess
+    code = """
+import warnings
+from utils.utils import set_seed
+from dataset import WaveTrainDataset, WaveEvalDataset, TrainDataLoader, EvalDataLoader
+from adhoc_driver import AdhocTrainer
+from models.conv_tasnet import ConvTasNet
+from criterion.sdr import NegSISDR
+from criterion.pit import PIT1d
+from driver import TrainerBase, TesterBase
+from utils.tasnet import choose_layer_norm
+from utils.filterbank import choose_filterbank
+from utils.model import choose_nonlinear
+with warnings.catch_warnings(record=True) as seen:
+    warnings.simplefilter("always")
+    from norm import GlobalLayerNorm, CumulativeLayerNorm1d
+    from conv import DepthwiseSeparableConv1d
+assert sum(issubclass(w.category, FutureWarning) for w in seen) == 2
+import speech_amd.models.conv_tasnet, speech_amd.criterion.pit, speech_amd.modules.norm, speech_amd.driver
+assert ConvTasNet is speech_amd.models.conv_tasnet.ConvTasNet
+assert PIT1d is speech_amd.criterion.pit.PIT1d
+assert GlobalLayerNorm is speech_amd.modules.norm.GlobalLayerNorm
+assert issubclass(AdhocTrainer, TrainerBase) and AdhocTrainer is speech_amd.driver.AdhocTrainer
+set_seed(111)
+m = ConvTasNet(16, 4, enc_basis='trainable', dec_basis='trainable', enc_nonlinear=None, sep_hidden_channels=8,
+               sep_bottleneck_channels=8, sep_skip_channels=8, sep_num_blocks=1, sep_num_layers=2, causal=False)
+assert 'separator.tdcn.net.0.net.0.separable_conv1d.depthwise_conv1d.weight' in m.state_dict()
+print('compat ok')
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "compat"))
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "compat ok" in r.stdout, r.stdout + r.stderr

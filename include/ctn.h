@@ -281,6 +281,11 @@ typedef struct {
     float* dx; int64_t lddx, dxbs;    /* dn1 */
     double* isums; float* icol; int64_t icol_ld;   /* norm-1 backward sums (+=) */
     float* dgamma1; float* dbeta1;
+    /* recompute_y2 != 0: y2 is not read (it may be NULL) but recomputed from x, w and `bias` (the forward's bias, NULL =
+     * none), which takes one of the four tensors off the kernel's HBM traffic.  Honoured for whole-row gLN launches
+     * (oflags NORMBWD, xflags PRELU|NORM, per-sample statistics, T <= 4096, P <= 4); any other launch needs y2. */
+    const float* bias;
+    int32_t recompute_y2; int32_t pad1;
 } ctn_dw_bwd_args;
 
 int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream);

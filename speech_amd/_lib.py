@@ -105,6 +105,7 @@ class DwBwdArgs(C.Structure):
         ("dx", _p), ("lddx", _i64), ("dxbs", _i64),
         ("isums", _p), ("icol", _p), ("icol_ld", _i64),
         ("dgamma1", _p), ("dbeta1", _p),
+        ("bias", _p), ("recompute_y2", _i32), ("pad1", _i32),
     ]
 
 

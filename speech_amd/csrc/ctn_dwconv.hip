@@ -41,6 +41,19 @@ __device__ __forceinline__ f32x4 lds_read4(const float* row, int off) {
     return r;
 }
 
+// The same for the whole-row kernels, which know off % 4 from their launch arguments alone (`rem`, a scalar): when it is
+// not zero, the two aligned vectors around the four floats are read and the pick is a scalar branch.  Reads up to
+// row[(off & ~3) + 7]: those kernels' rows carry 8 floats of slack behind the last tap.
+__device__ __forceinline__ f32x4 lds_read4s(const float* row, int off, int rem) {
+    const float* p = row + (off - rem);
+    const f32x4 lo = ctn_ld4(p);
+    if (rem == 0) return lo;
+    const f32x4 hi = ctn_ld4(p + 4);
+    if (rem == 1) return f32x4{lo[1], lo[2], lo[3], hi[0]};
+    if (rem == 2) return f32x4{lo[2], lo[3], hi[0], hi[1]};
+    return f32x4{lo[3], hi[0], hi[1], hi[2]};
+}
+
 // Per-frame statistics of 4 consecutive frames; gLN (st == 0) was hoisted to scalars by the caller.
 __device__ __forceinline__ void stat4(const float* p, int64_t sb, int64_t st, int b, int t, int T, float hoisted,
                                       float (&o)[4]) {
@@ -168,6 +181,88 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
         const float tot = ctn_block_sum<2>(v, red);
         if (tid < 2) atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
     }
+}
+
+// ------------------------------------------------------------------------------------------ forward, whole rows
+// The separator's hot case as straight-line code: per-sample statistics (gLN) or no norm at all, one block per
+// (batch, channel) row of up to 4 * FIT * NTH frames.  Every global load of the row is issued at the top of the
+// kernel from clamped addresses (validity by selects, no branch around a load), so a block has its whole 16 KB row in
+// flight at once and eight resident blocks per CU keep the memory pipe full; the kernel above stages a row in rounds
+// behind guarded loads, which the compiler turns into branches with full vmcnt waits.  The arithmetic is the same,
+// expression for expression, so both kernels produce identical outputs.
+constexpr int FIT = 4;                 // float4 per thread: rows of up to 4 * 256 * 4 = 4096 frames
+template <int P>
+__global__ __launch_bounds__(NTH) void dw_fwd_row_kernel(const ctn_dw_fwd_args a, const int lw, const int HL4) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[2 * (NTH / 64)];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int T = a.T, d = a.dilation, padL = a.pad_left;
+    const int tid = threadIdx.x;
+    const float* xrow = a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx;
+    f32x4 v[FIT];
+#pragma unroll
+    for (int j = 0; j < FIT; ++j) {
+        const int tq = min(4 * (tid + j * NTH), (int)a.ldx - 4);
+        v[j] = CTN_DW_LD(xrow + tq);
+    }
+    const bool norm = (a.xflags & CTN_XF_NORM) != 0;
+    const bool prelu_in = (a.xflags & CTN_XF_PRELU) != 0;
+    const bool do_stats = a.esums != nullptr;
+    const float ain = (prelu_in && a.alpha_in) ? a.alpha_in[0] : 1.f;
+    const float aout = a.alpha_out ? a.alpha_out[0] : 1.f;
+    const float mean0 = norm ? a.mean[(int64_t)b * a.ssb] : 0.f;
+    const float rstd0 = norm ? a.rstd[(int64_t)b * a.ssb] : 1.f;
+    const float g = norm ? a.gamma[c] : 1.f;
+    const float be = norm ? a.beta[c] : 0.f;
+    float w[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) w[k] = a.w[(int64_t)c * P + k];
+    const float bias = a.bias ? a.bias[c] : 0.f;
+    // zero padding on both sides of the row slots [HL4, HL4 + 4 * FIT * NTH)
+    for (int i = tid; i < HL4 / 4; i += NTH) ctn_st4(&lds[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int i = HL4 / 4 + FIT * NTH + tid; i < lw / 4; i += NTH) ctn_st4(&lds[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int j = 0; j < FIT; ++j) {
+        const int t = 4 * (tid + j * NTH);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = v[j][e];
+            if (prelu_in) u = ctn_prelu(u, ain);
+            if (norm) u = __builtin_fmaf((u - mean0) * rstd0, g, be);   // dw_bwd_gln_rc_kernel recomputes exactly this
+            o[e] = (t + e < T) ? u : 0.f;
+        }
+        ctn_st4(&lds[HL4 + t], o);
+    }
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    float* yrow = a.y + (int64_t)b * a.ybs + (int64_t)c * a.ldy;
+    int rem[P];                          // tap offsets modulo 4: HL4 and t are multiples of 4
+#pragma unroll
+    for (int k = 0; k < P; ++k) rem[k] = (k * d - padL) & 3;
+#pragma unroll
+    for (int j = 0; j < FIT; ++j) {
+        const int t = 4 * (tid + j * NTH);
+        if (t < T) {
+            const int base = HL4 + t - padL;
+            f32x4 o = {bias, bias, bias, bias};
+#pragma unroll
+            for (int k = 0; k < P; ++k) o += w[k] * lds_read4s(lds, base + k * d, rem[k]);
+            CTN_DW_ST(yrow + t, o);
+            if (do_stats) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = (t + e < T) ? ctn_prelu(o[e], aout) : 0.f;
+                    s1 += u;
+                    s2 += u * u;
+                }
+            }
+        }
+    }
+    if (!do_stats) return;
+    float sv[2] = {s1, s2};
+    const float tot = ctn_block_sum<2>(sv, red);
+    if (tid < 2) atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
 }
 
 // Per-frame sums of a block's time tile -> global rows col[0][t], col[1][t].  A thread holds four consecutive frames;
@@ -802,6 +897,164 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_kernel(const ctn_dw_bwd_args a
     if (tid >= 8 && tid < 8 + P) atomicAdd(a.dw + (int64_t)c * P + (tid - 8), tot);
 }
 
+// ------------------------------------------------------------------------------------------ backward, gLN rows, y2 recomputed
+// The same row-per-block backward, but the convolution output y2 is recomputed from the input row instead of being
+// read: three tensors cross HBM (x and dn2 in, dn1 out) instead of four.  The LDS row first holds the convolution's
+// actual input N -- gamma1 * xhat1 + beta1 inside the row, zero outside -- so that
+//   y2[t]  = bias + sum_k w[k] N[t + k d - padL]            (what the forward kernel computed, same expression order)
+//   dw[k]  = sum_t dy2[t] N[t + k d - padL]                 (no separate beta1 term: the padding zeros are in N)
+// and the taps fetched for y2 are used for dw in the same breath; then the SAME row is overwritten with dy2 for the
+// taps of the input gradient.  xhat1 and dy2 of a thread's own frames stay in registers (the thread that stages frame
+// t is the one that finishes it).  One LDS row of 17 KB instead of two: eight blocks per CU instead of four, i.e.
+// twice the rows in flight per CU, which is what a kernel of load / compute / store phases needs to keep HBM busy.
+// Phases: stage N | y2, dy2, dw | stage dy2 | dn1 and the norm-1 sums; three barriers.
+template <int P>
+__global__ __launch_bounds__(NTH) void dw_bwd_gln_rc_kernel(const ctn_dw_bwd_args a, const int lw, const int H4) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NV = 10 + P;
+    __shared__ float red[NV * (NTH / 64)];
+    float* row = lds;
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int T = a.T, d = a.dilation, padL = a.pad_left;
+    const int tid = threadIdx.x;
+    const int ldmin = (int)min(a.lddn2, a.ldx);
+    const float* dnrow = a.dn2 + (int64_t)b * a.dn2bs + (int64_t)c * a.lddn2;
+    const float* xrow = a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx;
+    f32x4 vdn[GIT], xh[GIT];
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) {
+        const int tq = min(4 * (tid + j * NTH), ldmin - 4);
+        xh[j] = CTN_DW_LD(xrow + tq);
+        vdn[j] = CTN_DW_LD(dnrow + tq);
+    }
+    const float a1 = a.alpha1[0], a2 = a.alpha2[0];
+    const float m2 = a.mean2[(int64_t)b * a.ssb2], r2 = a.rstd2[(int64_t)b * a.ssb2];
+    const float k1 = a.c1_2[(int64_t)b * a.ssb2], k2 = a.c2_2[(int64_t)b * a.ssb2];
+    const float m1 = a.mean1[(int64_t)b * a.ssb1], r1 = a.rstd1[(int64_t)b * a.ssb1];
+    const float g2 = a.gamma2[c], g1 = a.gamma1[c], be1 = a.beta1[c];
+    const float bias = a.bias ? a.bias[c] : 0.f;
+    float w[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) w[k] = a.w[(int64_t)c * P + k];
+    int remf[P], remb[P];                // tap offsets modulo 4 (H4 and t are multiples of 4): forward taps, backward taps
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        remf[k] = (k * d - padL) & 3;
+        remb[k] = (padL - k * d) & 3;
+    }
+    // the halos on both sides of the row slots stay zero through both uses of the row
+    for (int i = tid; i < H4 / 4; i += NTH) ctn_st4(&row[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int i = H4 / 4 + GIT * NTH + tid; i < lw / 4; i += NTH) ctn_st4(&row[4 * i], f32x4{0.f, 0.f, 0.f, 0.f});
+    // ---- phase 1: the convolution's input row
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) {
+        const int t = 4 * (tid + j * NTH);
+        f32x4 nv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = t + e < T;
+            const float h = (ctn_prelu(xh[j][e], a1) - m1) * r1;
+            xh[j][e] = valid ? h : 0.f;
+            nv[e] = valid ? __builtin_fmaf(h, g1, be1) : 0.f;
+        }
+        ctn_st4(&row[H4 + t], nv);
+    }
+    __syncthreads();
+    // ---- phase 2: y2, the gradient of the convolution output (kept in vdn), the tap gradients
+    float dgamma2 = 0.f, dbeta2 = 0.f, dbias = 0.f;
+    // slope gradient sum du * min(y2, 0) with du = A dn + k1 + xc k2 as three sums: the parts of du cancel, and so do
+    // the terms across the sample, so they are combined in fp64 per block instead of being rounded per element
+    float da_dn = 0.f, da_1 = 0.f, da_xc = 0.f;
+    float dwa[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) dwa[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) {
+        const int t = 4 * (tid + j * NTH);
+        f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            const int i0 = H4 + t;
+            f32x4 nk[P];
+            f32x4 y4 = {bias, bias, bias, bias};
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                nk[k] = lds_read4s(row, i0 + k * d - padL, remf[k]);
+                y4 += w[k] * nk[k];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = t + e < T;
+                const float dn = vdn[j][e], y2 = y4[e];
+                const float u = ctn_prelu(y2, a2);
+                const float xc = u - m2;
+                const float du = g2 * dn * r2 + k1 + xc * k2;
+                const float dy = y2 > 0.f ? du : a2 * du;
+                dgamma2 += valid ? dn * xc * r2 : 0.f;
+                dbeta2 += valid ? dn : 0.f;
+                const float yn = (valid && !(y2 > 0.f)) ? y2 : 0.f;
+                da_dn = __builtin_fmaf(dn, yn, da_dn);
+                da_1 += yn;
+                da_xc = __builtin_fmaf(xc, yn, da_xc);
+                dbias += valid ? dy : 0.f;
+                dv[e] = valid ? dy : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dwa[k] += dv[e] * nk[k][e];
+        }
+        vdn[j] = dv;
+    }
+    __syncthreads();              // every tap of N has been read: the row is free
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) ctn_st4(&row[H4 + 4 * (tid + j * NTH)], vdn[j]);
+    __syncthreads();
+    // ---- phase 3: the input gradient and the norm-1 backward sums
+    float dgamma1 = 0.f, dbeta1 = 0.f, s1 = 0.f, s2 = 0.f;
+    float* dxrow = a.dx + (int64_t)b * a.dxbs + (int64_t)c * a.lddx;
+#pragma unroll
+    for (int j = 0; j < GIT; ++j) {
+        const int t = 4 * (tid + j * NTH);
+        if (t < T) {
+            const int i0 = H4 + t;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < P; ++k) o += w[k] * lds_read4s(row, i0 - k * d + padL, remb[k]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (t + e < T) {
+                    const float g = g1 * o[e];
+                    dgamma1 += o[e] * xh[j][e];
+                    dbeta1 += o[e];
+                    s1 += g;
+                    s2 += g * xh[j][e];
+                }
+            }
+            CTN_DW_ST(dxrow + t, o);
+        }
+    }
+    float v[NV];
+    v[0] = dgamma2; v[1] = dbeta2; v[2] = dbias; v[3] = dgamma1; v[4] = dbeta1;
+    v[5] = da_dn; v[6] = s1; v[7] = s2; v[8] = da_1; v[9] = da_xc;
+#pragma unroll
+    for (int k = 0; k < P; ++k) v[10 + k] = dwa[k];
+    const float tot = ctn_block_sum<NV>(v, red);
+    if (tid == 0 && a.dgamma2) atomicAdd(a.dgamma2 + c, tot);
+    if (tid == 1 && a.dbeta2) atomicAdd(a.dbeta2 + c, tot);
+    if (tid == 2 && a.dbias) atomicAdd(a.dbias + c, tot);
+    if (tid == 3 && a.dgamma1) atomicAdd(a.dgamma1 + c, tot);
+    if (tid == 4 && a.dbeta1) atomicAdd(a.dbeta1 + c, tot);
+    // threads 5, 8, 9 hold the three slope sums: fold them on thread 5 through LDS
+    if (tid == 8 || tid == 9) red[tid - 8] = tot;
+    __syncthreads();
+    if (tid == 5 && a.dalpha2)
+        atomicAdd(a.dalpha2 + ctn_slot(), (double)g2 * (double)r2 * (double)tot + (double)k1 * (double)red[0] +
+                                                   (double)k2 * (double)red[1]);
+    if ((tid == 6 || tid == 7) && a.isums)
+        atomicAdd(a.isums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + (tid - 6), (double)tot);
+    if (tid >= 10 && tid < 10 + P) atomicAdd(a.dw + (int64_t)c * P + (tid - 10), tot);
+}
+
 bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
     return p && ctn_aligned16(p) && ld % 4 == 0 && bs % 4 == 0 && ld >= T;
 }
@@ -813,7 +1066,7 @@ void pick_tile(int T, int halo2, bool cln, int lds_rows, int* CG, int* TT, int* 
     if (cln) tt = tt < 4 * NTH ? tt : 4 * NTH;
     while (tt + halo2 + 3 > max_floats && tt > 256) tt = ((tt / 2) + 3) & ~3;
     *TT = tt;
-    *lw = ((tt + halo2 + 3 + 3) & ~3) + 4;   // + 4: slack for the unaligned two-vector tap reads
+    *lw = ((tt + halo2 + 3 + 3) & ~3) + 4;   // + 4: slack for the unaligned tap reads
     *CG = cln ? 8 : 1;
 }
 
@@ -848,6 +1101,27 @@ int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream) {
         CTN_CHECK_LAUNCH("ctn_dw_fwd");
         return CTN_OK;
     }
+    {   // whole-row kernel: per-sample statistics (gLN) or none on the input, gLN sums or none on the output
+        const bool in_ok = !(a.xflags & CTN_XF_NORM) || a.sst == 0;
+        const bool out_ok = !stats || (!a.cln && a.esums);
+        const int HL4 = (a.pad_left + 3) & ~3;
+        const int HR4 = ((a.P - 1) * a.dilation - a.pad_left + 3) & ~3;
+        const int lwr = HL4 + 4 * FIT * NTH + HR4 + 8;
+        if (in_ok && out_ok && a.P <= 4 && a.T >= 4 && a.T <= 4 * FIT * NTH && (size_t)lwr * 4 <= 60 * 1024 &&
+            a.C <= 65535 * 32 && a.batch <= 65535) {
+            dim3 gridr(a.C, a.batch);
+            const size_t shm = (size_t)lwr * 4;
+            hipStream_t s = (hipStream_t)stream;
+            switch (a.P) {
+                case 1: hipLaunchKernelGGL(dw_fwd_row_kernel<1>, gridr, dim3(NTH), shm, s, a, lwr, HL4); break;
+                case 2: hipLaunchKernelGGL(dw_fwd_row_kernel<2>, gridr, dim3(NTH), shm, s, a, lwr, HL4); break;
+                case 3: hipLaunchKernelGGL(dw_fwd_row_kernel<3>, gridr, dim3(NTH), shm, s, a, lwr, HL4); break;
+                default: hipLaunchKernelGGL(dw_fwd_row_kernel<4>, gridr, dim3(NTH), shm, s, a, lwr, HL4); break;
+            }
+            CTN_CHECK_LAUNCH("ctn_dw_fwd");
+            return CTN_OK;
+        }
+    }
     dim3 grid(ctn_cdiv(a.T, TT), ctn_cdiv(a.C, CG), a.batch);
     hipLaunchKernelGGL(dw_fwd_kernel, grid, dim3(NTH), (size_t)lw * 4, (hipStream_t)stream, a, CG, TT, lw);
     CTN_CHECK_LAUNCH("ctn_dw_fwd");
@@ -864,7 +1138,7 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
                     act_ok(a.dx, a.lddx, a.dxbs, a.T) && a.w && a.dw,
                 "ctn_dw_bwd: dn2 / x / dx layout");
     if (a.oflags & CTN_XF_NORMBWD)
-        CTN_REQUIRE(act_ok(a.y2, a.ldy2, a.y2bs, a.T) && a.mean2 && a.rstd2 && a.c1_2 && a.c2_2 && a.gamma2,
+        CTN_REQUIRE((a.recompute_y2 || act_ok(a.y2, a.ldy2, a.y2bs, a.T)) && a.mean2 && a.rstd2 && a.c1_2 && a.c2_2 && a.gamma2,
                     "ctn_dw_bwd: output-side NORMBWD needs y2, stats, gamma2");
     if (a.xflags & CTN_XF_NORM)
         CTN_REQUIRE(a.mean1 && a.rstd1 && a.gamma1 && a.beta1, "ctn_dw_bwd: input-side NORM needs stats, gamma1, beta1");
@@ -880,6 +1154,17 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
         if (full && a.P <= 4 && a.T <= 4 * GIT * NTH && (size_t)lwg * 8 <= 60 * 1024 && a.T >= 4) {
             dim3 grid(a.C, a.batch);
             const size_t shm = (size_t)lwg * 8;
+            if (a.recompute_y2) {
+                const size_t shm1 = (size_t)lwg * 4;          // one row
+                switch (a.P) {
+                    case 1: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<1>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
+                    case 2: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<2>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
+                    case 3: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<3>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
+                    default: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<4>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
+                }
+                CTN_CHECK_LAUNCH("ctn_dw_bwd");
+                return CTN_OK;
+            }
             switch (a.P) {
                 case 1: hipLaunchKernelGGL(dw_bwd_gln_kernel<1>, grid, dim3(NTH), shm, s, a, lwg, H4); break;
                 case 2: hipLaunchKernelGGL(dw_bwd_gln_kernel<2>, grid, dim3(NTH), shm, s, a, lwg, H4); break;
@@ -890,6 +1175,8 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
             return CTN_OK;
         }
     }
+    if (a.oflags & CTN_XF_NORMBWD)
+        CTN_REQUIRE(act_ok(a.y2, a.ldy2, a.y2bs, a.T), "ctn_dw_bwd: this launch cannot recompute y2, pass it");
     int CG, TT, lw;
     pick_tile(a.T, 2 * H, a.cln != 0, 2, &CG, &TT, &lw);
     CTN_REQUIRE((size_t)lw * 8 <= 64 * 1024, "ctn_dw_bwd: dilation halo too large for LDS");

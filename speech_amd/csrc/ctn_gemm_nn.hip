@@ -769,10 +769,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     }
     const bool has_aux = lo_use || hi_use;
     const int tl = min(t, (int)a.ldy - 4);                          // clamped column for the unconditional loads
+    // Rows >= split without an input of their own (a HEADS launch that writes instead of accumulating) must not be
+    // priced in rows of Y: Y holds only `split` rows there, and with more skip than residual channels the unconditional
+    // prefetch would read past the end of the last batch entry's Y.  They fetch row 0 of Y instead (value unused).
     auto aux_ptr = [&](int m) {
         const int mc = min(m, M - 1);
-        return mc < split ? lo_base + (int64_t)b * lo_bs + (int64_t)mc * lo_ld + tl
-                          : hi_base + (int64_t)b * hi_bs + (int64_t)(mc - split) * hi_ld + tl;
+        if (mc < split) return lo_base + (int64_t)b * lo_bs + (int64_t)mc * lo_ld + tl;
+        if (!hi_use) return (const float*)a.Y + (int64_t)b * a.ybs + tl;
+        return hi_base + (int64_t)b * hi_bs + (int64_t)(mc - split) * hi_ld + tl;
     };
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {

@@ -13,6 +13,8 @@ device memory, the current stream and the autograd graph edges.  Data flow of on
 
 Only y1, y2 and the per-norm statistics are kept for backward; normalised tensors never exist in HBM.
 """
+import os
+
 import torch
 
 from . import ops
@@ -21,6 +23,10 @@ from .ops import (XF_PRELU, XF_NORM, XF_NORMBWD, EPI_STORE, EPI_STATS, EPI_HEADS
 
 
 # ------------------------------------------------------------------------------------------------ helpers
+# The depthwise backward kernel recomputes the convolution output from the layer's first pre-activation instead of
+# reading the stored one (three tensors over HBM instead of four).  False restores the reading form (diagnostics, tests).
+RECOMPUTE_DW_OUTPUT = os.environ.get("CTN_DW_RECOMPUTE", "1") != "0"
+
 FLAT_ALIGN = 64      # floats: every tensor of a flat parameter / gradient buffer starts on a 256-byte boundary
 
 
@@ -55,6 +61,7 @@ class GradSink:
         self.views = [self.flat[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._alpha = []
+        self._folded = set()
         self.dalpha = None
 
     def g(self, p):
@@ -72,18 +79,27 @@ class GradSink:
     _index_cache = {}      # (device, slope indices, offsets) -> device index tensors; built once, so that a step
                            # has no host-to-device copy (a synchronisation point, and not capturable in a graph)
 
+    def fold_alphas(self, lo=0, hi=None):
+        """Adds the fp64 slope-gradient slots of the parameters with index in [lo, hi) that were handed out and not
+        folded yet into their fp32 views.  A region of the flat buffer is final -- ready to be all-reduced -- once every
+        kernel that adds to it has been enqueued and its slopes are folded."""
+        hi = len(self.params) if hi is None else hi
+        idx = tuple(sorted(i for i in set(self._alpha) if lo <= i < hi and i not in self._folded))
+        if not idx:
+            return
+        self._folded.update(idx)
+        dev = self.flat.device
+        key = (str(dev), idx, tuple(self.offsets[i] for i in idx))
+        hit = GradSink._index_cache.get(key)
+        if hit is None:
+            hit = (torch.tensor(key[1], device=dev, dtype=torch.long),
+                   torch.tensor(key[2], device=dev, dtype=torch.long))
+            GradSink._index_cache[key] = hit
+        src, dst = hit
+        self.flat.index_add_(0, dst, self.dalpha.index_select(0, src).sum(dim=1).float())
+
     def finish(self):
-        if self._alpha:
-            idx = tuple(sorted(set(self._alpha)))
-            dev = self.flat.device
-            key = (str(dev), idx, tuple(self.offsets[i] for i in idx))
-            hit = GradSink._index_cache.get(key)
-            if hit is None:
-                hit = (torch.tensor(key[1], device=dev, dtype=torch.long),
-                       torch.tensor(key[2], device=dev, dtype=torch.long))
-                GradSink._index_cache[key] = hit
-            src, dst = hit
-            self.flat.index_add_(0, dst, self.dalpha.index_select(0, src).sum(dim=1).float())
+        self.fold_alphas()
         return self.views
 
 
@@ -181,7 +197,7 @@ def layer_backward(L, saved, dout, dskip, sink, dilation, causal, eps):
                _pads(P, dilation, causal), xflags=XF_PRELU | XF_NORM, alpha1=L.a1, stat1=st1, gamma1=L.g1.view(-1),
                beta1=L.be1.view(-1), dgamma1=sink.g(o["g1"]).view(-1), dbeta1=sink.g(o["be1"]).view(-1), iacc=bacc1,
                y2=y2, alpha2=L.a2, stat2=st2, gamma2=L.g2.view(-1), dgamma2=sink.g(o["g2"]).view(-1),
-               dbeta2=sink.g(o["be2"]).view(-1), dalpha2=sink.alpha_slot(o["a2"]))
+               dbeta2=sink.g(o["be2"]).view(-1), dalpha2=sink.alpha_slot(o["a2"]), bias=L.bd, recompute_y2=RECOMPUTE_DW_OUTPUT)
     ops.bwd_coefs(bacc1, st1, B, H, T, eps)
     # bottleneck: input gradient (+ residual path) and weight gradient, norm-1 / PReLU-1 backward on load
     dx = new_act(B, Bc, T, dev)
@@ -515,8 +531,16 @@ def separator_backward(mp, w, saved, dz, sink, eps):
     ops.gemm_nn(Sc, T, M, B, mp.Wm.detach().view(M, Sc), Sc, dz, dskip, emode=EPI_PRELUBWD, E=skip,
                 ealpha=mp.a_sep.detach(), esums=sink.alpha_slot(mp.a_sep))
     dout = None
-    for (L, dil), sv in zip(reversed(mp.layers), reversed(saved_layers)):
+    # cfg["region_hook"](layer index): called after the backward of layer `index` has been enqueued, for the indices in
+    # cfg["region_layers"] -- the first layer of every TCN block but block 0.  Everything behind that layer in the
+    # parameter order is final then (the trainer starts that region's gradient exchange while the rest of the backward
+    # pass runs).
+    hook, hook_layers = cfg.get("region_hook"), cfg.get("region_layers", ())
+    for i in range(len(mp.layers) - 1, -1, -1):
+        (L, dil), sv = mp.layers[i], saved_layers[i]
         dout = layer_backward(L, sv, dout, dskip, sink, dil, causal, eps)
+        if hook is not None and i in hook_layers:
+            hook(i, sink)
     # separator bottleneck
     dn0 = new_act(B, N, T, dev)
     bacc0 = Accum(B, T, causal, dev)

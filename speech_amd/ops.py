@@ -375,7 +375,7 @@ def dw_fwd(x, w, bias, y, dilation, pad_left, *, xflags=0, alpha_in=None, stat=N
 
 def dw_bwd(dn2, x, w, dw, dbias, dx, dilation, pad_left, *, xflags=0, alpha1=None, stat1=None, gamma1=None,
            beta1=None, dgamma1=None, dbeta1=None, iacc=None, y2=None, alpha2=None, stat2=None, gamma2=None,
-           dgamma2=None, dbeta2=None, dalpha2=None):
+           dgamma2=None, dbeta2=None, dalpha2=None, bias=None, recompute_y2=False):
     lib = _lib.load()
     B, Cc, T = x.shape
     a = _lib.DwBwdArgs()
@@ -403,6 +403,10 @@ def dw_bwd(dn2, x, w, dw, dbias, dx, dilation, pad_left, *, xflags=0, alpha1=Non
     if iacc is not None:
         a.isums, a.icol, a.icol_ld = _ptr(iacc.sums), _ptr(iacc.col), iacc.ld
     a.dgamma1, a.dbeta1 = _ptr(dgamma1), _ptr(dbeta1)
+    # whole-row gLN launches can recompute the convolution output from x instead of reading it (see include/ctn.h);
+    # the library needs y2 for every other launch, so it is passed whenever there is one
+    rows_fit = T <= 4096 and w.shape[-1] <= 4 and not cln and stat1 is not None and stat2 is not None
+    a.bias, a.recompute_y2 = _ptr(bias), 1 if (recompute_y2 and rows_fit) else 0
     _lib.check(lib.ctn_dw_bwd(C.byref(a), _stream()), "ctn_dw_bwd")
 
 
@@ -463,7 +467,10 @@ def _check_signal_pair(est, tgt):
     """The loss kernels index the target with the estimate's sizes and strides: refuse anything else here, before a
     mismatched pair becomes a silent wrong loss or an out-of-bounds device read."""
     _require_cuda(est, tgt)
-    if (est.dim() != 3 or tgt.shape != est.shape or tgt.stride() != est.stride() or est.stride(2) != 1
+    # strides of size-1 dimensions are never multiplied by a non-zero index, so they may differ
+    strides_differ = est.dim() == 3 and tgt.dim() == 3 and any(
+        n > 1 and a != b for n, a, b in zip(est.shape, est.stride(), tgt.stride()))
+    if (est.dim() != 3 or tgt.shape != est.shape or strides_differ or (est.shape[2] > 1 and est.stride(2) != 1)
             or est.dtype != torch.float32 or tgt.dtype != torch.float32 or tgt.device != est.device):
         raise _lib.CtnError("loss kernels need estimate and target as fp32 (B, S, T) tensors of the same shape, strides "
                             "and device with unit time stride; got {} {} and {} {}".format(

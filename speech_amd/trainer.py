@@ -48,7 +48,7 @@ def shard_batch(mixture, sources, rank, world):
 
 class FlatTrainer:
     def __init__(self, model, criterion, lr=1e-3, max_norm=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 n_buckets=1, n_streams=1, use_graph=False):
+                 n_buckets=1, n_streams=1, use_graph=False, overlap_exchange=None):
         self.model, self.criterion = model, criterion
         self.lr, self.max_norm, self.betas, self.eps = lr, max_norm, betas, eps
         self.group = process_group
@@ -67,6 +67,13 @@ class FlatTrainer:
         self._graphs = {}
         self.max_graphs = 2
         self._eager_steps = 0
+        # overlap_exchange: the gradient buffer is all-reduced region by region while the backward pass is still
+        # running -- one region per TCN block, in the order the backward pass completes them (last block first) -- on
+        # the process group's own stream, instead of in one piece after the pass.  It needs the collectives between
+        # the kernel launches, so it applies to eager launches; with use_graph the whole pass is one graph replay and
+        # the exchange follows it (n_buckets pieces in flight together).  None = overlap whenever launches are eager.
+        self.overlap_exchange = overlap_exchange
+        self._pending = []
         if not model._fused_ok() or model.dec_basis != 'trainable':
             raise NotImplementedError("FlatTrainer drives the fused Conv-TasNet schedule with a trainable encoder / "
                                       "decoder pair only")
@@ -135,17 +142,88 @@ class FlatTrainer:
         graph.replay()
         return loss.clone(), perm.clone()
 
+    # ------------------------------------------------------------------ regions of the flat gradient buffer
+    def _region_table(self):
+        """[(first layer index or None, start, end)] in the order the backward pass completes them: the parameters of
+        TCN block r and everything behind them that is not in an earlier region.  Region 0 is the last block plus the
+        mask convolution and the decoder; the last region is block 0 plus the encoder, entry norm and bottleneck and is
+        complete only when the whole pass is."""
+        if getattr(self, "_regions", None) is not None:
+            return self._regions
+        cfg = self.model.fused_config()
+        R, X = cfg["sep_num_blocks"], cfg["sep_num_layers"]
+        n_dual, n_single = 14, 12                      # parameters per residual layer (functional.Layer.NAMES_*)
+        assert len(self.params) == 5 + (R * X - 1) * n_dual + n_single + 4
+        total = self.flat_g.numel()
+        regions, end = [], total
+        for r in range(R - 1, 0, -1):
+            first = 5 + r * X * n_dual                # parameter index of block r's first layer
+            regions.append((r * X, self.offsets[first], end, first))
+            end = self.offsets[first]
+        regions.append((None, 0, end, 0))
+        self._regions = regions
+        return regions
+
+    def _overlapping(self):
+        if self.world == 1:
+            return False
+        if self.overlap_exchange is None:
+            return not self.use_graph
+        return bool(self.overlap_exchange) and not self.use_graph
+
+    def _exchange_region(self, start, end, ready_streams):
+        """All-reduce flat_g[start:end] once every stream in `ready_streams` has reached this point of its work."""
+        chunk = self.flat_g[start:end]
+        if self._prep is None:
+            self._prep = torch.cuda.Stream(device=self.flat_p.device)
+        for st in ready_streams:
+            self._prep.wait_stream(st)
+        if dist.get_backend(self.group) == "gloo":     # rehearsal without RCCL: blocking, through the host
+            self._prep.synchronize()
+            host = chunk.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            with torch.cuda.stream(self._prep):
+                chunk.copy_(host)
+            self._pending.append(self._prep.record_event())
+            return
+        with torch.cuda.stream(self._prep):            # the collective's stream starts behind _prep, i.e. behind the streams
+            self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _finish_exchange(self):
+        """The current stream waits for every region's collective."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    _prep = None
+
     def _forward_backward(self, mixture, sources):
         B = mixture.shape[0]
         n = min(self.n_streams, B)
         for p in self.params:
             p.grad = None
+        overlap = self._overlapping()
+        regions = self._region_table() if overlap else []
+        hook_layers = {first: k for k, (first, _, _, _) in enumerate(regions) if first is not None}
+        self._exchanged = False
         if n == 1:
+            main = torch.cuda.current_stream()
             cfg = self.model.fused_config()
             cfg["grad_flat"], cfg["grad_detached"] = self.flat_g, True
+            if overlap:
+                def hook(layer, sink):
+                    _, start, end, first_param = regions[hook_layers[layer]]
+                    sink.fold_alphas(first_param, None)
+                    self._exchange_region(start, end, [main])
+                cfg["region_hook"], cfg["region_layers"] = hook, set(hook_layers)
             out = ConvTasNetFn.apply(mixture, cfg, *self.params)
             loss, perm = self.criterion(out, sources)
             loss.backward()
+            if overlap:
+                _, start, end, _ = regions[-1]
+                self._exchange_region(start, end, [main])
+                self._finish_exchange()
+                self._exchanged = True
             return loss.detach(), perm
         if self.streams is None:
             self.streams = [torch.cuda.Stream(device=self.flat_p.device) for _ in range(self.n_streams)]
@@ -162,6 +240,16 @@ class FlatTrainer:
             with torch.cuda.stream(st):
                 cfg = self.model.fused_config()
                 cfg["grad_flat"], cfg["grad_zero"], cfg["grad_detached"] = self.flat_g, False, True
+                if overlap:
+                    # every sub-batch folds its own slope gradients when it closes a region; the region is exchanged
+                    # when the LAST sub-batch has closed it (the host enqueues the sub-batches one after the other, so
+                    # by then the earlier streams' work on the region is already in their queues)
+                    def hook(layer, sink, last=(i == n - 1), done=self.streams[:i + 1]):
+                        _, start, end, first_param = regions[hook_layers[layer]]
+                        sink.fold_alphas(first_param, None)
+                        if last:
+                            self._exchange_region(start, end, done)
+                    cfg["region_hook"], cfg["region_layers"] = hook, set(hook_layers)
                 out = ConvTasNetFn.apply(mixture[lo:hi], cfg, *self.params)
                 loss_i, perm_i = self.criterion(out, sources[lo:hi])
                 loss_i = loss_i * ((hi - lo) / B)  # mean over the sub-batch -> share of the shard mean
@@ -170,10 +258,16 @@ class FlatTrainer:
                 perms.append(perm_i)
         for i in range(n):
             main.wait_stream(self.streams[i])
+        if overlap:
+            _, start, end, _ = regions[-1]
+            self._exchange_region(start, end, [main])
+            self._finish_exchange()
+            self._exchanged = True
         return torch.stack(losses).sum(), torch.cat(perms, dim=0)
 
     def reduce_gradients(self):
-        if self.world == 1:
+        if self.world == 1 or getattr(self, "_exchanged", False):   # one rank, or exchanged during the backward pass
+            self._exchanged = False
             return
         allreduce_flat(self.flat_g, self.n_buckets, self.group)
 

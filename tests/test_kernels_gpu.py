@@ -328,6 +328,47 @@ def test_depthwise_plain(d, P, pad_left, T):
     assert_close(bg.grad, b.grad, 5e-5, "dw db")
 
 
+@pytest.mark.parametrize("d,pad_left,T", [(1, 1, 3999), (2, 2, 3999), (8, 16, 3999), (128, 128, 3999), (64, 128, 4096),
+                                          (3, 3, 1001), (1, 0, 5)])
+def test_depthwise_backward_recomputed_output_matches_stored(d, pad_left, T):
+    """The whole-row gLN backward kernel in its two forms -- reading the stored convolution output, and recomputing it
+    from the input row (three tensors over HBM instead of four) -- on the forward kernel's own output and statistics:
+    every gradient agrees to the kernel bar.  (A recomputed pre-activation can differ from the stored one only if the
+    two kernels round differently; they are written expression for expression alike.)"""
+    from speech_amd import ops
+    B, H, P = 3, 20, 3
+    x = act(rnd((B, H, T), 70))
+    dn2 = act(rnd((B, H, T), 71))
+    w, bias = rnd((H, P), 72).float().to(dev()), rnd((H,), 73).float().to(dev())
+    g1, be1, g2 = (rnd((H,), 74 + i).float().to(dev()) for i in range(3))
+    a1 = torch.tensor([0.25], device=dev())
+    a2 = torch.tensor([0.1], device=dev())
+    u1 = prelu(x.double().cpu(), 0.25)
+    st1 = make_stat(*gln_stats(u1), False)
+    y2 = ops.new_act(B, H, T, dev())
+    acc2 = ops.Accum(B, T, False, dev())
+    ops.dw_fwd(x, w, bias, y2, d, pad_left, xflags=ops.XF_PRELU | ops.XF_NORM, alpha_in=a1, stat=st1, gamma=g1, beta=be1,
+               alpha_out=a2, acc=acc2)
+    st2 = ops.finalize_stats(acc2, B, H, T, 1e-12, dev())
+    st2.c1 = rnd((B,), 80).float().to(dev()) * 0.01
+    st2.c2 = rnd((B,), 81).float().to(dev()) * 0.01
+    outs = []
+    for recompute in (False, True):
+        dw, db = torch.zeros(H, P, device=dev()), torch.zeros(H, device=dev())
+        dg1, dbe1, dg2, dbe2 = (torch.zeros(H, device=dev()) for _ in range(4))
+        da2 = torch.zeros(ops._lib.STAT_SLOTS, device=dev(), dtype=torch.float64)
+        iacc = ops.Accum(B, T, False, dev())
+        dx = ops.new_act(B, H, T, dev())
+        ops.dw_bwd(dn2, x, w, dw, db, dx, d, pad_left, xflags=ops.XF_PRELU | ops.XF_NORM, alpha1=a1, stat1=st1, gamma1=g1,
+                   beta1=be1, dgamma1=dg1, dbeta1=dbe1, iacc=iacc, y2=y2, alpha2=a2, stat2=st2, gamma2=g2, dgamma2=dg2,
+                   dbeta2=dbe2, dalpha2=da2, bias=bias, recompute_y2=recompute)
+        torch.cuda.synchronize()
+        outs.append(dict(dx=dx.clone(), dw=dw, db=db, dg1=dg1, dbe1=dbe1, dg2=dg2, dbe2=dbe2, da2=da2.sum().reshape(1),
+                         isums=iacc.sums.sum(dim=1)))
+    for k in outs[0]:
+        assert_close(outs[1][k], outs[0][k], TOL, "recomputed vs stored: " + k)
+
+
 @pytest.mark.parametrize("L,S,T,relu", [(16, 8, 1000, False), (16, 8, 32000, True), (2, 1, 500, False), (16, 4, 403, True),
                                         (16, 8, 16, False),       # one frame
                                         (16, 16, 4096, True),     # no overlap between frames

@@ -1,0 +1,87 @@
+"""FlatTrainer with two ranks: both on cuda:0 over gloo (the multi-rank control flow of the data-parallel step -- weight
+broadcast, region-wise exchange during the backward pass, bucketed exchange after a graph replay, clip after the
+reduction -- without a second GPU).  Every exchange schedule must leave both ranks with the same parameters, and those
+must equal a single process's update on the global batch (egs/wsj0-mix/common/src/driver.py:146-155 semantics)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (name, n_streams, use_graph, overlap_exchange, n_buckets)
+VARIANTS = [("eager_overlap", 1, False, True, 1), ("eager_after", 1, False, False, 1),
+            ("streams2_overlap", 2, False, True, 1), ("graph_buckets4", 2, True, None, 4)]
+STEPS = 4
+
+
+def _paths():
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _train(variant, world, rank, device):
+    import cases
+    import convtasnet_oracle as O
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    from speech_amd.trainer import FlatTrainer, shard_batch
+    from test_parity_gpu import build, load_state
+    _, n_streams, use_graph, overlap, n_buckets = variant
+    cfg = dict(O.CONFIG_SMALL, sep_num_blocks=3, sep_num_layers=2)       # three regions
+    model = load_state(build(cfg), cases.e2e_state(cfg))
+    if rank > 0:                                   # the constructor's broadcast must make the replicas identical
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01)
+    tr = FlatTrainer(model, PIT1d(NegSISDR(), 2), lr=1e-3, max_norm=5.0, n_streams=n_streams, use_graph=use_graph,
+                     overlap_exchange=overlap, n_buckets=n_buckets)
+    losses = []
+    for i in range(STEPS):
+        mixture, sources = cases.e2e_batch(cfg, 4, 4000, 50 + i)
+        if world > 1:
+            mixture, sources = shard_batch(mixture, sources, rank, world)
+        loss, _ = tr.step(mixture.to(device), sources.to(device))
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, losses
+
+
+def _worker(rank, world, port, out_dir):
+    _paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    device = torch.device("cuda", 0)
+    out = {}
+    for variant in VARIANTS:
+        params, losses = _train(variant, world, rank, device)
+        out[variant[0]] = dict(params=params, losses=losses)
+        dist.barrier()
+    torch.save(out, os.path.join(out_dir, "rank{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_every_exchange_schedule_equals_global_batch(tmp_path):
+    _paths()
+    world, port = 2, 29700 + (os.getpid() % 2000)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank{}.pt".format(r)), weights_only=True) for r in range(world)]
+    single, single_losses = _train(("single", 1, False, False, 1), 1, 0, torch.device("cuda", 0))
+    for name, *_ in VARIANTS:
+        p0, p1 = ranks[0][name]["params"], ranks[1][name]["params"]
+        mean_loss = [(a + b) / 2 for a, b in zip(ranks[0][name]["losses"], ranks[1][name]["losses"])]
+        for a, b in zip(mean_loss, single_losses):     # mean of the shard means = global-batch mean
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (name, mean_loss, single_losses)
+        for k in single:
+            assert torch.equal(p0[k], p1[k]), "{}: ranks diverged on {}".format(name, k)
+            d = (p0[k] - single[k]).abs().max().item()
+            # four Adam steps; gradients are summed in a different order (atomics, two shards), and a step moves a weight by
+            # about lr * sign-like(g), so a rounding-level change of a near-zero gradient component shows at the 1e-5 level
+            assert d <= 2e-5, "{}: {} differs from the global-batch update by {}".format(name, k, d)

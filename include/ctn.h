@@ -354,6 +354,18 @@ int ctn_dwconv_generic_bwd(const float* x, int64_t xbs, int64_t ldx, int batch, 
 int ctn_pit_sisdr_fwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
                       float eps, int fixed_perm, double* work, float* pair, float* loss_b, int64_t* perm,
                       float* coef, void* stream);
+/* ctn_pit_sisdr_fwd without the `work` argument.  No counterpart in the reference: it is for callers that cannot
+ * allocate device memory or bring a workspace -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  The sums live in a device array built into the library (CTN_PIT_NOALLOC_MAX_WORK doubles = 512 KiB,
+ * held by every GPU the library is used on until the process ends); the call clears the part it uses on `stream` and
+ * then enqueues the same three kernels.  It calls no allocator.  batch * (2*S*S + S) beyond the array is rejected with
+ * CTN_ERR_ARG.  All calls on one GPU share the array: calls that overlap on one GPU (different streams, or threads)
+ * race; serialise them or use ctn_pit_sisdr_fwd.  The first call on a device resolves the array's device address
+ * (hipGetSymbolAddress), so make that one outside graph capture. */
+#define CTN_PIT_NOALLOC_MAX_WORK 65536
+int ctn_pit_sisdr_fwd_noalloc(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
+                              float eps, int fixed_perm, float* pair, float* loss_b, int64_t* perm, float* coef,
+                              void* stream);
 /* dest[b][i][t] = gscale[b*gs_bstride + i*gs_istride] * (a*tgt[b][p(i)][t] + c*est[b][i][t]) */
 int ctn_pit_sisdr_bwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
                       const int64_t* perm, const float* coef, const float* gscale, int gs_bstride, int gs_istride,

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("CTN_LIB", os.path.join(_HERE, "libctn_hip.so"))   # C
 
 XF_PRELU, XF_NORM, XF_NORMBWD = 1, 2, 4
 STAT_SLOTS = 32          # CTN_STAT_SLOTS of include/ctn.h
+PIT_NOALLOC_MAX_WORK = 65536   # CTN_PIT_NOALLOC_MAX_WORK of include/ctn.h
 EPI_STORE, EPI_STATS, EPI_HEADS, EPI_SIGMOID, EPI_PRELUBWD, EPI_NORMBWD, EPI_ADD = range(7)
 
 _p = C.c_void_p
@@ -150,6 +151,8 @@ PROTOTYPES = {
                                   _i64, _p]),
     "ctn_pit_sisdr_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, _p, _p, _p, _p, _p,
                                     _p]),
+    "ctn_pit_sisdr_fwd_noalloc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, _p, _p, _p, _p,
+                                            _p]),
     "ctn_pit_sisdr_bwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, C.c_int, C.c_int, _p,
                                     _i64, _i64, _p]),
     "ctn_dwconv_generic_fwd": (C.c_int, [_p, _i64, _i64, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int,

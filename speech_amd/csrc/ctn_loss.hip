@@ -8,7 +8,15 @@
 // sums are fp32 over a few dozen samples, everything above that is accumulated in fp64, so the S! candidate
 // losses are accurate to fp32 rounding and the arg-min reproduces the reference's choice, with exact ties
 // (bit-identical candidates) resolved to the first permutation like torch.min.
+#include <mutex>
+
 #include "ctn_common.h"
+
+// Work area of ctn_pit_sisdr_fwd_noalloc: the dot products and residual energies the two passes accumulate, for callers
+// that cannot bring a workspace of their own.  Every GPU the library runs on holds its own copy of this array until the
+// process ends; host code reaches it only through the per-device address resolved in pit_scratch_ptr() below (the
+// array's name is a host-side stand-in, not a device address).
+static __device__ __align__(256) double scratch[CTN_PIT_NOALLOC_MAX_WORK];
 
 namespace {
 
@@ -234,9 +242,76 @@ __global__ __launch_bounds__(NTH) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Device address of `scratch` on the current device, resolved once per device (with that device current) and kept.
+constexpr int MAX_DEVICES = 64;
+double* g_scratch_ptr[MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+int pit_scratch_ptr(double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        ctn_set_error("ctn_pit_sisdr_fwd_noalloc: hipGetDevice failed or device index %d out of range (%s)", dev,
+                      hipGetErrorString(e));
+        return CTN_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        double* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            ctn_set_error("ctn_pit_sisdr_fwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev,
+                          hipGetErrorString(e));
+            return CTN_ERR_LAUNCH;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return CTN_OK;
+}
+
+template <int S>
+void pit_launch(const float* est, const float* tgt, int batch, int T, int64_t ss, int64_t bs, float eps, int fixed_perm,
+                double* work, float* pair, float* loss_b, int64_t* perm, float* coef, hipStream_t s) {
+    dim3 grid(ctn_cdiv(T, CHUNK), batch);
+    hipLaunchKernelGGL(pit_pass1_kernel<S>, grid, dim3(NTH), 0, s, est, tgt, T, ss, bs, work);
+    hipLaunchKernelGGL(pit_pass2_kernel<S>, grid, dim3(NTH), 0, s, est, tgt, T, ss, bs, eps, work, 0);
+    hipLaunchKernelGGL(pit_finalize_kernel<S>, dim3(ctn_cdiv(batch, 64)), dim3(64), 0, s, work, batch, eps, fixed_perm,
+                       pair, loss_b, perm, coef);
+}
+
 }  // namespace
 
 extern "C" {
+
+int ctn_pit_sisdr_fwd_noalloc(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs,
+                              float eps, int fixed_perm, float* pair, float* loss_b, int64_t* perm, float* coef,
+                              void* stream) {
+    CTN_REQUIRE(est && tgt && pair && loss_b && perm && coef, "ctn_pit_sisdr_fwd_noalloc: null pointer");
+    CTN_REQUIRE(batch > 0 && T > 0 && S >= 1 && S <= 4, "ctn_pit_sisdr_fwd_noalloc: supports 1..4 sources");
+    const int64_t need = (int64_t)batch * (2 * S * S + S);
+    CTN_REQUIRE(need <= CTN_PIT_NOALLOC_MAX_WORK,
+                "ctn_pit_sisdr_fwd_noalloc: batch * (2*S*S + S) = %lld exceeds the built-in work area of %d doubles "
+                "(use ctn_pit_sisdr_fwd with a workspace of your own)", (long long)need, CTN_PIT_NOALLOC_MAX_WORK);
+    double* work = nullptr;
+    const int rc = pit_scratch_ptr(&work);
+    if (rc != CTN_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // the array keeps the previous call's sums: the part this call accumulates into starts at zero
+    hipError_t e = hipMemsetAsync(work, 0, (size_t)need * sizeof(double), s);
+    if (e != hipSuccess) {
+        ctn_set_error("ctn_pit_sisdr_fwd_noalloc: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        return CTN_ERR_LAUNCH;
+    }
+    switch (S) {
+        case 1: pit_launch<1>(est, tgt, batch, T, ss, bs, eps, fixed_perm, work, pair, loss_b, perm, coef, s); break;
+        case 2: pit_launch<2>(est, tgt, batch, T, ss, bs, eps, fixed_perm, work, pair, loss_b, perm, coef, s); break;
+        case 3: pit_launch<3>(est, tgt, batch, T, ss, bs, eps, fixed_perm, work, pair, loss_b, perm, coef, s); break;
+        default: pit_launch<4>(est, tgt, batch, T, ss, bs, eps, fixed_perm, work, pair, loss_b, perm, coef, s); break;
+    }
+    CTN_CHECK_LAUNCH("ctn_pit_sisdr_fwd_noalloc");
+    return CTN_OK;
+}
 
 int ctn_pit_sisdr_fwd(const float* est, const float* tgt, int batch, int S, int T, int64_t ss, int64_t bs, float eps,
                       int fixed_perm, double* work, float* pair, float* loss_b, int64_t* perm, float* coef,

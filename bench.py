@@ -13,8 +13,8 @@ The line also carries
                 instrumented step: algorithmic FLOPs of its launches / their summed duration, vs the 157.3
                 TFLOP/s dense f32 matrix peak of MI355X;
   roofline_hbm  the same for the fused depthwise kernels against the 8 TB/s HBM3E peak
-                (algorithmic bytes: forward 2 x H x T' x 4, backward 3 x H x T' x 4 per utterance and layer; the
-                backward kernel moves a fourth tensor, reported beside it), with the rate of a hand-written 16-byte
+                (algorithmic bytes: forward 2 x H x T' x 4, backward 3 x H x T' x 4 per utterance and layer), with the
+                rate of a hand-written 16-byte
                 copy kernel and of the bare f32-MFMA loop measured in the same process as yardsticks;
   cpu_baseline  the CPU oracle (a PyTorch restatement of the reference's step) timed on this host.
 """
@@ -71,8 +71,8 @@ def instrumented_step(trainer, mixture, sources):
     ops.gemm_nn = wrap("gemm_nn", lambda M, T, K, batch, *a, **k: 2.0 * M * T * K * batch)
     ops.gemm_nt = wrap("gemm_nt", lambda M, N, T, batch, *a, **k: 2.0 * M * N * T * batch)
     ops.dw_fwd = wrap("dw_fwd", lambda x, w, bias, y, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
-    # the contract prices the backward kernel at 3 tensors (read x, read dy, write dx); the kernel also reads the saved
-    # convolution output instead of recomputing it, 4 tensors moved -- both fractions are reported
+    # the backward kernel is priced at 3 tensors (read x, read dy, write dx), which is what it moves: the convolution
+    # output is recomputed from x instead of being read
     ops.dw_bwd = wrap("dw_bwd", lambda dn2, x, *a, **k: 3.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
     # per-kernel timing needs eager launches on ONE stream (two sub-batch streams overlap kernels, which makes a
     # kernel's own duration meaningless); the work is the same full per-GPU batch
@@ -93,7 +93,7 @@ def instrumented_step(trainer, mixture, sources):
 
 
 def traffic_file(batch):
-    return "profiles/r1_bench_b{}_pmc_traffic.json".format(batch)
+    return "profiles/r2_bench_b{}_pmc_traffic.json".format(batch)
 
 
 def profiled_traffic(prefix, batch):
@@ -304,21 +304,25 @@ def main():
     dt = t.item()
     final_loss = float(losses[-1].item()) if losses else float("nan")
 
-    # Informational extra measurements, never `value`: the same K steps with the GEMM products on the bf16 MFMA from
-    # operands split into bf16 pieces (opt-in modes, ctn_gemm_set_split).  One-GPU runs only: the multi-GPU runs measure
-    # scaling of the headline mode and nothing else.
+    # Informational extra measurements, never `value`: the same K steps in the two other arithmetic modes of the GEMMs
+    # (CTN_ARITH_* in include/ctn.h) -- plain f32 MFMAs, and two bf16 pieces per operand.  One-GPU runs only: the
+    # multi-GPU runs measure scaling of the headline mode and nothing else.
+    from speech_amd import ops as _ops
+    headline_split = _ops.get_gemm_split()
     split_probe = None
     if world == 1 and not args.no_split_probe:
-        from speech_amd import ops as _ops
-        notes = {2: "opt-in mode, not the headline: GEMM products as hi*hi + hi*lo + lo*hi of two bf16 pieces per operand "
-                    "on the bf16 MFMA, fp32 accumulation; waveforms and loss stay within 1e-4 of the reference "
-                    "(tests/test_split_gpu.py)",
-                 3: "opt-in mode, not the headline: three bf16 pieces per operand (an exact representation of the fp32 "
-                    "value) and the six leading products on the bf16 MFMA, fp32 accumulation; meets the f32-MFMA mode's "
-                    "GEMM bounds (tests/test_split_gpu.py)"}
+        notes = {0: "informational, not the headline: the same step with the GEMM products on v_mfma_f32_32x32x2_f32",
+                 2: "opt-in throughput mode, not the headline: GEMM products as hi*hi + hi*lo + lo*hi of two bf16 pieces "
+                    "per operand on the bf16 MFMA, fp32 accumulation; each GEMM within 5e-5 instead of 2e-5 of exact "
+                    "math, waveforms and loss within 1e-4 of the reference (tests/test_split_gpu.py)",
+                 3: "informational: three bf16 pieces per operand (an exact representation of the fp32 value) and the "
+                    "six leading products on the bf16 MFMA, fp32 accumulation"}
+        names = {0: "f32_mfma", 2: "bf16_two_pieces", 3: "bf16_three_pieces_exact"}
         split_probe = {}
         try:
-            for pieces in (2, 3):
+            for pieces in (0, 2, 3):
+                if pieces == headline_split:
+                    continue
                 _ops.set_gemm_split(pieces)
                 trainer._graphs.clear()            # captured graphs hold the kernels of the mode they were captured in
                 trainer._eager_steps = 0
@@ -330,15 +334,12 @@ def main():
                     loss_s, _ = trainer.step(*batches[i % n_batches])
                 barrier()
                 dts = time.perf_counter() - t1
-                ts = torch.tensor([dts], device="cpu" if rehearsal else device, dtype=torch.float64)
-                if world > 1:
-                    dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-                split_probe["pieces_%d" % pieces] = dict(
-                    value=round(args.batch * world * args.steps / ts.item(), 3), unit="utt/s",
-                    ms_per_step=round(ts.item() / args.steps * 1e3, 3), final_loss=round(float(loss_s.item()), 4),
+                split_probe[names[pieces]] = dict(
+                    value=round(args.batch * world * args.steps / dts, 3), unit="utt/s",
+                    ms_per_step=round(dts / args.steps * 1e3, 3), final_loss=round(float(loss_s.item()), 4),
                     note=notes[pieces])
         finally:
-            _ops.set_gemm_split(0)
+            _ops.set_gemm_split(headline_split)
             trainer._graphs.clear()
             trainer._eager_steps = 0
 
@@ -373,25 +374,58 @@ def main():
     if not args.no_roofline:
         # every rank runs the instrumented step: it contains the gradient all-reduce, a collective
         prof = instrumented_step(trainer, *batches[0])
+    prof_f32 = None
+    if prof is not None and headline_split != 0:
+        # the same instrumented step with the products on f32 MFMAs: the instruction the f32 matrix peak is quoted for
+        _ops.set_gemm_split(0)
+        try:
+            prof_f32 = instrumented_step(trainer, *batches[0])
+        finally:
+            _ops.set_gemm_split(headline_split)
     if rank == 0 and prof is not None:
-        gn = prof["gemm_nn"]
-        gt = prof["gemm_nt"]
-        a = gn["work"] / (gn["ms"] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="gemm_nn_fast_kernel (f32 MFMA 32x32x2, pointwise conv fwd + dgrad)",
-                    achieved=round(a, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(a / PEAK_F32_MFMA_TFLOPS, 4), traffic=profiled_traffic("gemm_nn_fast_kernel", args.batch),
-                    traffic_source=traffic_file(args.batch),
-                    mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph is the profiled command)",
-                    launches_per_step=gn["launches"],
-                    avg_launch_us=round(gn["ms"] * 1e3 / gn["launches"], 1),
-                    mfma_bare_loop=round(mfma_bare_loop_rate(device), 1),
-                    plain_gemm_on_random_operands=round(plain_gemm_rate(device, False), 1),
-                    plain_gemm_on_constant_operands=round(plain_gemm_rate(device, True), 1))
-        b = gt["work"] / (gt["ms"] * 1e-3) / 1e12
-        extra["roofline_wgrad"] = dict(bound="mfma", kernel="gemm_nt_fast_kernel (weight gradients)", achieved=round(b, 2),
-                                       peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                                       frac=round(b / PEAK_F32_MFMA_TFLOPS, 4), launches_per_step=gt["launches"],
-                                       avg_launch_us=round(gt["ms"] * 1e3 / gt["launches"], 1))
+        PEAK_BF16_MFMA_TFLOPS = 2500.0
+        products = {0: 1, 2: 3, 3: 6}[headline_split]      # bf16 instruction work per algorithmic product
+
+        def gemm_rows(pr, pieces):
+            rows = {}
+            for key, kernel in (("gemm_nn", "gemm_nn_fast_kernel (pointwise conv fwd + dgrad)"),
+                                ("gemm_nt", "gemm_nt_fast_kernel (weight gradients)")):
+                g = pr[key]
+                rate = g["work"] / (g["ms"] * 1e-3) / 1e12
+                row = dict(bound="mfma", kernel=kernel, achieved=round(rate, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                           frac=round(rate / PEAK_F32_MFMA_TFLOPS, 4), launches_per_step=g["launches"],
+                           avg_launch_us=round(g["ms"] * 1e3 / g["launches"], 1))
+                if pieces:
+                    n = {2: 3, 3: 6}[pieces]
+                    row["instructions"] = "v_mfma_f32_32x32x16_bf16, {} per algorithmic fp32 product tile".format(n)
+                    row["bf16_mfma_issue_rate"] = dict(achieved=round(rate * n, 1), peak=PEAK_BF16_MFMA_TFLOPS,
+                                                       frac=round(rate * n / PEAK_BF16_MFMA_TFLOPS, 4), unit="TFLOP/s")
+                else:
+                    row["instructions"] = "v_mfma_f32_32x32x2_f32"
+                rows[key] = row
+            return rows
+
+        rows = gemm_rows(prof, headline_split)
+        roof = rows["gemm_nn"]
+        roof.update(
+            note="achieved = algorithmic fp32 FLOPs (2*M*K*T' per launch and utterance) / summed launch durations; peak = the "
+                 "dense f32 matrix peak, the peak of the dtype the path computes in",
+            traffic=profiled_traffic("gemm_nn_fast_kernel", args.batch), traffic_source=traffic_file(args.batch),
+            mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph "
+                 "is the profiled command)",
+            mfma_bare_loop=round(mfma_bare_loop_rate(device), 1))
+        extra["roofline_wgrad"] = rows["gemm_nt"]
+        if prof_f32 is not None:
+            rows32 = gemm_rows(prof_f32, 0)
+            rows32["gemm_nn"].update(plain_gemm_on_random_operands=None, plain_gemm_on_constant_operands=None)
+            _ops.set_gemm_split(0)
+            try:
+                rows32["gemm_nn"]["plain_gemm_on_random_operands"] = round(plain_gemm_rate(device, False), 1)
+                rows32["gemm_nn"]["plain_gemm_on_constant_operands"] = round(plain_gemm_rate(device, True), 1)
+            finally:
+                _ops.set_gemm_split(headline_split)
+            extra["roofline_f32_mfma_mode"] = dict(pointwise=rows32["gemm_nn"], wgrad=rows32["gemm_nt"],
+                                                   kernel_ms_per_step={k: round(v["ms"], 3) for k, v in prof_f32.items()})
         copy_gbs = device_copy_rate(device)
         rw2_gbs = device_2r1w_rate(device)
         hb = []
@@ -406,10 +440,9 @@ def main():
                                     "3 x H x T' x 4 per utterance (read x, read dy, write dx)",
                        copy_kernel_rate=round(copy_gbs, 1), two_read_one_write_kernel_rate=round(rw2_gbs, 1),
                        frac_of_copy_kernel=round(gbs / copy_gbs, 4))
-            if name == "dw_bwd":      # what the kernel moves: it reads the saved convolution output as a fourth tensor
-                moved = gbs * 4.0 / 3.0
-                row["moved_bytes"] = dict(achieved=round(moved, 1), frac=round(moved / PEAK_HBM_GBS, 4),
-                                          frac_of_two_read_one_write_kernel=round(moved / rw2_gbs, 4))
+            if name == "dw_bwd":
+                row["note"] = ("the kernel recomputes the convolution output from x instead of reading the stored one, so "
+                               "it moves the three tensors it is priced at")
             hb.append(row)
         roof_hbm = hb
         step_ms = dt / args.steps * 1e3
@@ -435,6 +468,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "arithmetic": {0: "f32 MFMA (v_mfma_f32_32x32x2_f32)",
+                           2: "fp32 operands split into two bf16 pieces, three products on the bf16 MFMA, fp32 accumulation",
+                           3: "fp32 in, fp32 out, fp32 accumulation; GEMM products from an EXACT split of every fp32 operand "
+                              "into three bf16 pieces, six products on v_mfma_f32_32x32x16_bf16 (what is dropped is below one "
+                              "fp32 rounding of the product); every parity test of the suite runs in this mode"}[headline_split],
             "data": "synthetic",
             "config": {"workload": "Conv-TasNet paper config N512 L16 B128 H512 Sc128 P3 X8 R3 gLN, 2 speakers, "
                                    "32000-sample (4 s @ 8 kHz) mixtures, full training step "
@@ -443,7 +481,7 @@ def main():
                        "parallelism": "dp{}".format(world), "sub_batch_streams": args.streams,
                        "hip_graph": bool(args.graph), "final_loss": round(final_loss, 4)},
             "recipe_batch_2": recipe,
-            "split_bf16_mode": split_probe,
+            "other_arithmetic_modes": split_probe,
             "roofline": roof,
             "roofline_hbm": roof_hbm,
             "cpu_baseline": cpu,

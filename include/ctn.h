@@ -71,22 +71,23 @@ int ctn_sizeof_gemm_nt_args(void);
 int ctn_sizeof_dw_fwd_args(void);
 int ctn_sizeof_dw_bwd_args(void);
 
-/* Tuning aid without a counterpart in the reference: forces the column width of the pointwise-GEMM output tile
- * (64 or 128; 0 = choose per launch, the default).  Results agree across widths to fp32 summation order.
- * Process-wide; returns CTN_ERR_ARG for any other value. */
-int ctn_gemm_nn_set_tile(int width);
-
-/* Opt-in arithmetic modes without a counterpart in the reference: the products of ctn_gemm_nn and ctn_gemm_nt run on the
- * bf16 MFMA from operands split into bf16 pieces, with fp32 accumulation, instead of on f32 MFMAs.
- *   pieces = 2 (or 1): x = hi + lo (17 mantissa bits, pieces rounded to nearest), three instructions per tile -- hi*hi +
- *     hi*lo + lo*hi.  Each GEMM then agrees with fp32 arithmetic to about 1e-5 of its largest output instead of 1e-6.
- *   pieces = 3: x = hi + mid + lo exactly (each piece the next eight significant bits), six instructions per tile -- every
- *     product except mid*lo, lo*mid and lo*lo, which are below 2^-21 of the largest.  Meets the f32-MFMA bounds.
- *   pieces = 0: f32 MFMAs, the default.
- * CTN_GEMM_SPLIT=<pieces> in the environment selects the mode at first use.  Process-wide; returns CTN_ERR_ARG for any
- * other value. */
-int ctn_gemm_set_split(int pieces);
-int ctn_gemm_get_split(void);
+/* Arithmetic of the products of ctn_gemm_nn / ctn_gemm_nt (field `arith` of their argument structs).  The library
+ * keeps no mode of its own: every call says what it wants, so calls with different modes can be in flight together and
+ * a captured graph holds exactly what its calls asked for.
+ *   CTN_ARITH_DEFAULT (0): the same as CTN_ARITH_BF16X3.
+ *   CTN_ARITH_F32:    v_mfma_f32_32x32x2_f32 on the fp32 operands.
+ *   CTN_ARITH_BF16X3: every fp32 operand is split into three bf16 pieces, x = hi + mid + lo EXACTLY (each piece the next
+ *       eight significant bits), and the six products of pieces above 2^-22 of the largest run on
+ *       v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  No operand is rounded; what is left out (mid*lo, lo*mid, lo*lo)
+ *       is of the size of one fp32 rounding of the product.  Meets the same bounds as CTN_ARITH_F32 in every test.
+ *   CTN_ARITH_BF16X2: x = hi + lo (17 mantissa bits, pieces rounded to nearest) and three products.  Each GEMM then
+ *       agrees with fp32 arithmetic to about 1e-5 of its largest output instead of 1e-6: a throughput mode for callers
+ *       who accept that.
+ * The register-staged kernels for small or unaligned shapes always use CTN_ARITH_F32. */
+#define CTN_ARITH_DEFAULT 0
+#define CTN_ARITH_F32 1
+#define CTN_ARITH_BF16X2 2
+#define CTN_ARITH_BF16X3 3
 
 /* Measurement aids without a counterpart in the reference: the rates the GPU itself sustains, for the benchmark to
  * report beside the kernels' own.
@@ -145,6 +146,8 @@ typedef struct {
     float* Y2; int64_t ldy2, y2bs;    /* HEADS rows >= Mo */
     int32_t accumulate;               /* HEADS: Y2 += instead of = */
     int32_t tile_width;               /* output-tile columns of the LDS-DMA kernel: 0 = choose, 64 or 128 */
+    int32_t arith;                    /* CTN_ARITH_* */
+    int32_t pad0;
     const float* ealpha;              /* STATS / PRELUBWD / NORMBWD slope (NULL = 1, i.e. no PReLU) */
     double* esums;                    /* [batch][CTN_STAT_SLOTS][2] (+=), PRELUBWD: [CTN_STAT_SLOTS] */
     float* ecol; int64_t ecol_bs, ecol_ld;   /* cLN: [batch][2][ecol_ld] column sums (+=) */
@@ -178,6 +181,8 @@ typedef struct {
     const float* B; int64_t ldb, bbs;
     int32_t bflags;                           /* CTN_XF_PRELU | CTN_XF_NORM */
     int32_t kchunk;                           /* time steps per block, multiple of 32 */
+    int32_t arith;                            /* CTN_ARITH_* */
+    int32_t pad0;
     const float* b_alpha;
     const float* b_mean; const float* b_rstd; int64_t b_ssb, b_sst;
     const float* b_gamma; const float* b_beta;

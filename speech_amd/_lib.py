@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTN_LIB", os.path.join(_HERE, "libctn_hip.so"))   # CTN_LIB: diagnostic builds only
 
 XF_PRELU, XF_NORM, XF_NORMBWD = 1, 2, 4
+ARITH_DEFAULT, ARITH_F32, ARITH_BF16X2, ARITH_BF16X3 = 0, 1, 2, 3     # CTN_ARITH_* of include/ctn.h
 STAT_SLOTS = 32          # CTN_STAT_SLOTS of include/ctn.h
 PIT_NOALLOC_MAX_WORK = 65536   # CTN_PIT_NOALLOC_MAX_WORK of include/ctn.h
 EPI_STORE, EPI_STATS, EPI_HEADS, EPI_SIGMOID, EPI_PRELUBWD, EPI_NORMBWD, EPI_ADD = range(7)
@@ -42,7 +43,7 @@ class GemmNNArgs(C.Structure):
         ("emode", _i32), ("Mo", _i32),
         ("R", _p), ("ldr", _i64), ("rbs", _i64),
         ("Y2", _p), ("ldy2", _i64), ("y2bs", _i64),
-        ("accumulate", _i32), ("tile_width", _i32),
+        ("accumulate", _i32), ("tile_width", _i32), ("arith", _i32), ("pad0", _i32),
         ("ealpha", _p), ("esums", _p),
         ("ecol", _p), ("ecol_bs", _i64), ("ecol_ld", _i64),
         ("E", _p), ("lde", _i64), ("ebs", _i64),
@@ -64,7 +65,7 @@ class GemmNTArgs(C.Structure):
         ("a_gamma", _p),
         ("a_rowsum", _p), ("a_rowsum2", _p), ("a_dalpha", _p),
         ("B", _p), ("ldb", _i64), ("bbs", _i64),
-        ("bflags", _i32), ("kchunk", _i32),
+        ("bflags", _i32), ("kchunk", _i32), ("arith", _i32), ("pad0", _i32),
         ("b_alpha", _p),
         ("b_mean", _p), ("b_rstd", _p), ("b_ssb", _i64), ("b_sst", _i64),
         ("b_gamma", _p), ("b_beta", _p),
@@ -114,9 +115,6 @@ class DwBwdArgs(C.Structure):
 PROTOTYPES = {
     "ctn_version": (C.c_char_p, []),
     "ctn_last_error": (C.c_char_p, []),
-    "ctn_gemm_nn_set_tile": (C.c_int, [C.c_int]),
-    "ctn_gemm_set_split": (C.c_int, [C.c_int]),
-    "ctn_gemm_get_split": (C.c_int, []),
     "ctn_sizeof_gemm_nn_args": (C.c_int, []),
     "ctn_sizeof_gemm_nt_args": (C.c_int, []),
     "ctn_sizeof_dw_fwd_args": (C.c_int, []),

@@ -908,14 +908,19 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_kernel(const ctn_dw_bwd_args a
 // t is the one that finishes it).  One LDS row of 17 KB instead of two: eight blocks per CU instead of four, i.e.
 // twice the rows in flight per CU, which is what a kernel of load / compute / store phases needs to keep HBM busy.
 // Phases: stage N | y2, dy2, dw | stage dy2 | dn1 and the norm-1 sums; three barriers.
-template <int P>
+// AL: dilation and left padding are multiples of 4, so every tap is one aligned 16-byte LDS read and the loops carry no
+// alignment branches (they would fence the scheduling of the reads of different taps).
+// DD, PL: dilation and left padding as compile-time constants (0 = take them from the arguments).  With them the
+// unaligned taps of the small dilations -- three aligned reads per phase and a pick of four registers each -- cost no
+// instructions at all: the picks become register names.  Instantiated for the non-causal dilations 1 and 2.
+template <int P, bool AL, int DD = 0, int PL = 0>
 __global__ __launch_bounds__(NTH) void dw_bwd_gln_rc_kernel(const ctn_dw_bwd_args a, const int lw, const int H4) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = 10 + P;
     __shared__ float red[NV * (NTH / 64)];
     float* row = lds;
     const int b = blockIdx.y, c = blockIdx.x;
-    const int T = a.T, d = a.dilation, padL = a.pad_left;
+    const int T = a.T, d = DD ? DD : a.dilation, padL = DD ? PL : a.pad_left;
     const int tid = threadIdx.x;
     const int ldmin = (int)min(a.lddn2, a.ldx);
     const float* dnrow = a.dn2 + (int64_t)b * a.dn2bs + (int64_t)c * a.lddn2;
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_rc_kernel(const ctn_dw_bwd_arg
             f32x4 y4 = {bias, bias, bias, bias};
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                nk[k] = lds_read4s(row, i0 + k * d - padL, remf[k]);
+                nk[k] = AL ? ctn_ld4(row + i0 + k * d - padL) : lds_read4s(row, i0 + k * d - padL, remf[k]);
                 y4 += w[k] * nk[k];
             }
 #pragma unroll
@@ -1010,7 +1015,9 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_rc_kernel(const ctn_dw_bwd_arg
     for (int j = 0; j < GIT; ++j) ctn_st4(&row[H4 + 4 * (tid + j * NTH)], vdn[j]);
     __syncthreads();
     // ---- phase 3: the input gradient and the norm-1 backward sums
-    float dgamma1 = 0.f, dbeta1 = 0.f, s1 = 0.f, s2 = 0.f;
+    // the norm-1 backward sums of this row are g1 * (sum dn1) and g1 * (sum dn1 * xhat1): the per-channel gradients
+    // times gamma1, so they need no accumulators of their own
+    float dgamma1 = 0.f, dbeta1 = 0.f;
     float* dxrow = a.dx + (int64_t)b * a.dxbs + (int64_t)c * a.lddx;
 #pragma unroll
     for (int j = 0; j < GIT; ++j) {
@@ -1019,15 +1026,13 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_rc_kernel(const ctn_dw_bwd_arg
             const int i0 = H4 + t;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < P; ++k) o += w[k] * lds_read4s(row, i0 - k * d + padL, remb[k]);
+            for (int k = 0; k < P; ++k)
+                o += w[k] * (AL ? ctn_ld4(row + i0 - k * d + padL) : lds_read4s(row, i0 - k * d + padL, remb[k]));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (t + e < T) {
-                    const float g = g1 * o[e];
                     dgamma1 += o[e] * xh[j][e];
                     dbeta1 += o[e];
-                    s1 += g;
-                    s2 += g * xh[j][e];
                 }
             }
             CTN_DW_ST(dxrow + t, o);
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_rc_kernel(const ctn_dw_bwd_arg
     }
     float v[NV];
     v[0] = dgamma2; v[1] = dbeta2; v[2] = dbias; v[3] = dgamma1; v[4] = dbeta1;
-    v[5] = da_dn; v[6] = s1; v[7] = s2; v[8] = da_1; v[9] = da_xc;
+    v[5] = da_dn; v[6] = g1 * dbeta1; v[7] = g1 * dgamma1; v[8] = da_1; v[9] = da_xc;
 #pragma unroll
     for (int k = 0; k < P; ++k) v[10 + k] = dwa[k];
     const float tot = ctn_block_sum<NV>(v, red);
@@ -1156,12 +1161,19 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
             const size_t shm = (size_t)lwg * 8;
             if (a.recompute_y2) {
                 const size_t shm1 = (size_t)lwg * 4;          // one row
-                switch (a.P) {
-                    case 1: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<1>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
-                    case 2: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<2>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
-                    case 3: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<3>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
-                    default: hipLaunchKernelGGL(dw_bwd_gln_rc_kernel<4>, grid, dim3(NTH), shm1, s, a, lwg, H4); break;
-                }
+                const bool al = ((a.dilation | a.pad_left) & 3) == 0;
+#define CTN_RC_CASE(PP)                                                                                             \
+    case PP:                                                                                                        \
+        if (al) hipLaunchKernelGGL((dw_bwd_gln_rc_kernel<PP, true>), grid, dim3(NTH), shm1, s, a, lwg, H4);          \
+        else hipLaunchKernelGGL((dw_bwd_gln_rc_kernel<PP, false>), grid, dim3(NTH), shm1, s, a, lwg, H4);            \
+        break;
+                if (a.P == 3 && a.dilation == 1 && a.pad_left == 1)
+                    hipLaunchKernelGGL((dw_bwd_gln_rc_kernel<3, false, 1, 1>), grid, dim3(NTH), shm1, s, a, lwg, H4);
+                else if (a.P == 3 && a.dilation == 2 && a.pad_left == 2)
+                    hipLaunchKernelGGL((dw_bwd_gln_rc_kernel<3, false, 2, 2>), grid, dim3(NTH), shm1, s, a, lwg, H4);
+                else
+                    switch (a.P) { CTN_RC_CASE(1) CTN_RC_CASE(2) CTN_RC_CASE(3) default: CTN_RC_CASE(4) }
+#undef CTN_RC_CASE
                 CTN_CHECK_LAUNCH("ctn_dw_bwd");
                 return CTN_OK;
             }

@@ -920,19 +920,12 @@ size_t fast_lds_bytes(const ctn_gemm_nn_args& a, int width) {
     return floats * sizeof(float);
 }
 
-// Tile width: ctn_gemm_nn_set_tile() or CTN_GEMM_FBN=64|128 forces one (tuning aids).  Otherwise the width whose
+// Tile width: the caller's tile_width (64 or 128) if given.  Otherwise the width whose
 // blocks fill whole generations of the chip's block slots best (all blocks of a launch take the same time, so a
 // partly filled last generation is pure tail); the wide tile wins ties, it re-reads less.  Slots per CU: 4 by
 // registers, fewer when a width's LDS footprint does not fit four times into the CU's 160 KB (the wide tile with
 // the norm-backward operand: 3).
-int g_forced_fbn = -1;
 int pick_fbn(const ctn_gemm_nn_args& a) {
-    if (g_forced_fbn < 0) {
-        const char* e = getenv("CTN_GEMM_FBN");
-        const int v = e ? atoi(e) : 0;
-        g_forced_fbn = (v == 64 || v == 128) ? v : 0;
-    }
-    if (g_forced_fbn) return g_forced_fbn;
     if (a.tile_width == 64 || a.tile_width == 128) return a.tile_width;
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -953,15 +946,9 @@ int pick_fbn(const ctn_gemm_nn_args& a) {
     return fill(128) >= fill(64) - 0.02 ? 128 : 64;
 }
 
-// Split-bf16 products (see gemm_nn_fast_kernel): off unless ctn_gemm_set_split(1) was called or CTN_GEMM_SPLIT=1 is set.
-int g_split = -1;
-int gemm_split() {
-    if (g_split < 0) {
-        const char* e = getenv("CTN_GEMM_SPLIT");
-        const int v = e ? atoi(e) : 0;
-        g_split = (v == 1 || v == 2) ? 2 : (v == 3 ? 3 : 0);
-    }
-    return g_split;
+// pieces per operand of the call's arithmetic mode: 0 (f32 MFMA), 2 or 3 (bf16 MFMA on split operands)
+int gemm_split(int arith) {
+    return arith == CTN_ARITH_F32 ? 0 : (arith == CTN_ARITH_BF16X2 ? 2 : 3);
 }
 
 template <int FBN_>
@@ -975,7 +962,7 @@ int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
     const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
     const size_t shmem = fast_lds_bytes(a, FBN_);
     const dim3 grid((unsigned)total), block(NTH);
-    const int split = gemm_split();
+    const int split = gemm_split(a.arith);
 #define CTN_NN_SPLIT_CASES(SP)                                                                                          \
     do {                                                                                                                \
         if (bwd) {                                                                                                      \
@@ -1050,24 +1037,12 @@ int launch(const ctn_gemm_nn_args& a, int vecA, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int ctn_gemm_set_split(int pieces) {
-    CTN_REQUIRE(pieces == 0 || pieces == 1 || pieces == 2 || pieces == 3, "ctn_gemm_set_split: 0 (off), 2 or 3 pieces (1 = 2)");
-    g_split = pieces == 1 ? 2 : pieces;
-    return CTN_OK;
-}
-
-extern "C" int ctn_gemm_get_split(void) { return gemm_split(); }
-
-extern "C" int ctn_gemm_nn_set_tile(int width) {
-    CTN_REQUIRE(width == 0 || width == 64 || width == 128, "ctn_gemm_nn_set_tile: width must be 0, 64 or 128");
-    g_forced_fbn = width;
-    return CTN_OK;
-}
-
 extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
     CTN_REQUIRE(args, "ctn_gemm_nn: null args");
     const ctn_gemm_nn_args& a = *args;
     CTN_REQUIRE(a.M > 0 && a.T > 0 && a.K > 0 && a.batch > 0, "ctn_gemm_nn: empty problem");
+    CTN_REQUIRE(a.arith >= CTN_ARITH_DEFAULT && a.arith <= CTN_ARITH_BF16X3, "ctn_gemm_nn: arith is one of CTN_ARITH_*");
+    CTN_REQUIRE(a.tile_width == 0 || a.tile_width == 64 || a.tile_width == 128, "ctn_gemm_nn: tile_width is 0, 64 or 128");
     CTN_REQUIRE(a.A && a.X && a.Y, "ctn_gemm_nn: null A / X / Y");
     CTN_REQUIRE(a.K1 >= 0 && a.K1 <= a.K, "ctn_gemm_nn: K1 out of range");
     CTN_REQUIRE(a.K1 == a.K || (a.A2 && a.Xb), "ctn_gemm_nn: split K needs A2 and Xb");

@@ -284,7 +284,7 @@ __device__ __forceinline__ void nt_split_bf16_3(const float (&x)[8], ntbf16x8& h
 
 // SPLIT = 2: products on the bf16 MFMA from operands split into two bf16 pieces (hi*hi + hi*lo + lo*hi, fp32
 // accumulation), one instruction triple per 16 frames instead of eight f32 MFMAs; SPLIT = 3: three pieces and the six
-// leading products (all 24 mantissa bits).  See ctn_gemm_set_split.
+// leading products (all 24 mantissa bits).  See CTN_ARITH_* in include/ctn.h.
 template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN, int SPLIT = 0>
 __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
                                                            const int tiles_n, const int nchunks) {
@@ -785,7 +785,7 @@ void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const unsigned total = (unsigned)tiles_m * tiles_n * nchunks * a.batch;
     const size_t tile_floats = (size_t)(TM + TN + (BWD ? TM : 0)) * FK;
     const size_t shmem = (BWD ? 3 : 2) * tile_floats * sizeof(float);
-    const int split = ctn_gemm_get_split();
+    const int split = a.arith == CTN_ARITH_F32 ? 0 : (a.arith == CTN_ARITH_BF16X2 ? 2 : 3);
     const bool rows = stat_rows(a);
 #define CTN_NT_LAUNCH(CLN_, SP)                                                                                        \
     hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, CLN_, SP>), dim3(total), dim3(NTH), shmem, s, a,     \

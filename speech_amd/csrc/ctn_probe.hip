@@ -1,41 +1,38 @@
 // Measurement aids: what the chip itself sustains, measured with the simplest kernels that can reach it, so that the
 // roofline fractions reported for the real kernels have a yardstick taken on the same GPU in the same process.
-//   copy / 2-read-1-write : 16-byte non-temporal loads and stores, grid-stride, nothing else
+//   copy / 2-read-1-write : 16-byte non-temporal loads and stores, one block per contiguous 16 KiB, nothing else
 //   bare MFMA loop        : v_mfma_f32_32x32x2_f32 back to back on four independent accumulators per wave, operands in
 //                           registers (loaded once from random data), no LDS or memory traffic inside the loop
 #include "ctn_common.h"
 
 namespace {
 
+// One block per contiguous 16 KiB chunk (1024 float4), every thread's four loads issued before its four stores: the
+// access pattern of a whole-row streaming kernel, and the fastest of the plain-copy patterns tried on this GPU
+// (grid-stride loops over the same buffers are 10-20 % slower).
 __global__ __launch_bounds__(256) void probe_copy_kernel(const f32x4* __restrict__ a, f32x4* __restrict__ y, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // four independent 16-byte loads in flight per thread before the first store
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f32x4 v0 = __builtin_nontemporal_load(a + i);
-        const f32x4 v1 = __builtin_nontemporal_load(a + i + stride);
-        const f32x4 v2 = __builtin_nontemporal_load(a + i + 2 * stride);
-        const f32x4 v3 = __builtin_nontemporal_load(a + i + 3 * stride);
-        __builtin_nontemporal_store(v0, y + i);
-        __builtin_nontemporal_store(v1, y + i + stride);
-        __builtin_nontemporal_store(v2, y + i + 2 * stride);
-        __builtin_nontemporal_store(v3, y + i + 3 * stride);
-    }
-    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), y + i);
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(a + (base + u * 256 < n4 ? base + u * 256 : n4 - 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n4) __builtin_nontemporal_store(v[u], y + base + u * 256);
 }
 
 __global__ __launch_bounds__(256) void probe_2r1w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
                                                          f32x4* __restrict__ y, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + stride < n4; i += 2 * stride) {
-        const f32x4 a0 = __builtin_nontemporal_load(a + i), b0 = __builtin_nontemporal_load(b + i);
-        const f32x4 a1 = __builtin_nontemporal_load(a + i + stride), b1 = __builtin_nontemporal_load(b + i + stride);
-        __builtin_nontemporal_store(a0 + b0, y + i);
-        __builtin_nontemporal_store(a1 + b1, y + i + stride);
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    f32x4 va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256 < n4 ? base + u * 256 : n4 - 1;
+        va[u] = __builtin_nontemporal_load(a + i);
+        vb[u] = __builtin_nontemporal_load(b + i);
     }
-    for (; i < n4; i += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(a + i) + __builtin_nontemporal_load(b + i), y + i);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n4) __builtin_nontemporal_store(va[u] + vb[u], y + base + u * 256);
 }
 
 __global__ __launch_bounds__(256) void probe_mfma_f32_kernel(const float* __restrict__ in, float* out, int iters) {
@@ -66,7 +63,8 @@ extern "C" {
 int ctn_probe_copy(const float* a, const float* b, float* y, int64_t n, void* stream) {
     CTN_REQUIRE(a && y && n > 0 && n % 4 == 0 && ctn_aligned16(a) && ctn_aligned16(y) && (!b || ctn_aligned16(b)),
                 "ctn_probe_copy: needs 16-byte aligned buffers and n %% 4 == 0");
-    const int blocks = 256 * 8;
+    CTN_REQUIRE(n / 4 <= (int64_t)1024 * 0x7fffffff, "ctn_probe_copy: n too large");
+    const unsigned blocks = (unsigned)((n / 4 + 1023) / 1024);
     if (b)
         hipLaunchKernelGGL(probe_2r1w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a,
                            (const f32x4*)b, (f32x4*)y, n / 4);

@@ -7,6 +7,7 @@ stride whose row and batch strides are multiples of 4 floats ("act" layout,
 see new_act); anything else is copied into that layout first.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -147,18 +148,48 @@ class Accum:
 
 
 # ------------------------------------------------------------------------------------------------ arithmetic mode
+# The library keeps no mode: every GEMM call carries its arithmetic (CTN_ARITH_* in include/ctn.h) and tile width in its
+# argument struct.  What this module passes by default lives HERE, on the caller's side of the C ABI:
+#   pieces 3 (the default): fp32 operands split exactly into three bf16 pieces, six products on the bf16 MFMA, fp32
+#       accumulation -- the f32-MFMA bounds hold in every test;
+#   pieces 0: f32 MFMAs;  pieces 2: two pieces, three products (each GEMM within 5e-5 instead of 2e-5 of exact math).
+# CTN_GEMM_SPLIT=<pieces> in the environment sets the initial value.
+def _initial_split():
+    v = os.environ.get("CTN_GEMM_SPLIT", "3").strip()
+    return {"0": 0, "1": 2, "2": 2, "3": 3}.get(v, 3)
+
+
+_gemm_split = _initial_split()
+_gemm_tile = 0
+
+
 def set_gemm_split(pieces):
-    """Process-wide: run the products of the pointwise and weight-gradient GEMMs on the bf16 MFMA from operands split
-    into bf16 pieces, with fp32 accumulation, instead of f32 MFMAs; see ctn_gemm_set_split in include/ctn.h.
-    pieces: 0 / False = off (the default), 2 / True = two pieces and three products, 3 = three pieces and six products
-    (all 24 mantissa bits).  HIP graphs captured before the switch keep the kernels they captured."""
+    """Arithmetic of the GEMM calls made through this module from now on: 0 / False = f32 MFMAs, 2 / True = two bf16
+    pieces and three products, 3 = three pieces and six products (all 24 mantissa bits; the default).  HIP graphs captured
+    earlier keep the calls they captured."""
+    global _gemm_split
     level = 2 if pieces is True else int(pieces)
-    _lib.check(_lib.load().ctn_gemm_set_split(level), "ctn_gemm_set_split")
+    if level not in (0, 2, 3):
+        raise ValueError("pieces is 0 (f32 MFMA), 2 or 3")
+    _gemm_split = level
 
 
 def get_gemm_split():
-    """0 (off), 2 or 3: the number of bf16 pieces per operand the GEMMs currently use."""
-    return int(_lib.load().ctn_gemm_get_split())
+    """0 (f32 MFMAs), 2 or 3: the number of bf16 pieces per operand the GEMM calls of this module use."""
+    return _gemm_split
+
+
+def set_gemm_tile(width):
+    """Forces the output-tile width (64 or 128 columns) of the pointwise GEMM's LDS-DMA kernel for calls made through this
+    module; 0 = let the library choose per launch (the default).  A tuning and testing aid."""
+    global _gemm_tile
+    if width not in (0, 64, 128):
+        raise ValueError("width is 0, 64 or 128")
+    _gemm_tile = width
+
+
+def _arith():
+    return {0: _lib.ARITH_F32, 2: _lib.ARITH_BF16X2, 3: _lib.ARITH_BF16X3}[_gemm_split]
 
 
 # ------------------------------------------------------------------------------------------------ chunking
@@ -264,7 +295,8 @@ def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, 
     """Y[b] = A(k-major) . xform(X[b]); see ctn_gemm_nn in include/ctn.h.  X/Xb/X2/Y/Y2/R/E are act views."""
     lib = _lib.load()
     a = _lib.GemmNNArgs()
-    a.tile_width = tile_width
+    a.tile_width = tile_width or _gemm_tile
+    a.arith = _arith()
     a.M, a.T, a.K, a.batch = M, T, K, batch
     a.A, a.lda = _ptr(A), lda
     a.A2, a.lda2 = _ptr(A2), lda2
@@ -317,6 +349,7 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
     """C[m][n] += sum_b,t xformA(A)[b][m][t] * xformB(B)[b][n][t]; see ctn_gemm_nt in include/ctn.h."""
     lib = _lib.load()
     a = _lib.GemmNTArgs()
+    a.arith = _arith()
     a.M, a.N, a.T, a.batch = M, N, T, batch
     a.M1 = M if M1 is None else M1
     if A is not None:

@@ -22,12 +22,11 @@ PATHS = ["generic", "fast64", "fast128"]
 
 @pytest.fixture
 def gemm_path(request):
-    from speech_amd import _lib
-    lib = _lib.load()
+    from speech_amd import ops
     path = request.param
-    assert lib.ctn_gemm_nn_set_tile({"generic": 0, "fast64": 64, "fast128": 128}[path]) == 0
+    ops.set_gemm_tile({"generic": 0, "fast64": 64, "fast128": 128}[path])
     yield path
-    lib.ctn_gemm_nn_set_tile(0)
+    ops.set_gemm_tile(0)
 
 
 def act(t):
@@ -85,8 +84,7 @@ def test_transpose():
                                          (32, 512, 100, 3), (64, 64, 64, 1)])
 @pytest.mark.parametrize("width", [64, 128])
 def test_gemm_nn_plain(M, K, T, batch, width):
-    from speech_amd import ops, _lib
-    _lib.load().ctn_gemm_nn_set_tile(width)
+    from speech_amd import ops
     W = rnd((M, K), 2)
     bias = rnd((M,), 3)
     X = rnd((batch, K, T), 4)
@@ -94,9 +92,8 @@ def test_gemm_nn_plain(M, K, T, batch, width):
     Wt = torch.empty(K, M, device=dev())
     ops.transpose(W.float().to(dev()), Wt, M)
     Y = ops.new_act(batch, M, T, dev())
-    ops.gemm_nn(M, T, K, batch, Wt, M, act(X), Y, bias=bias.float().to(dev()))
+    ops.gemm_nn(M, T, K, batch, Wt, M, act(X), Y, bias=bias.float().to(dev()), tile_width=width)
     torch.cuda.synchronize()
-    _lib.load().ctn_gemm_nn_set_tile(0)
     assert_close(Y, ref, TOL, "gemm_nn")
 
 

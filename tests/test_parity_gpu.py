@@ -385,8 +385,16 @@ def test_ragged_minimal_and_long_inputs_vs_float64(cfg_name, batch, T):
     assert torch.equal(perm.cpu(), perm64)
     assert_close(out, out64, TOL, "out")
     assert_close(loss.reshape(1), loss64.reshape(1), TOL, "loss")
+    # Scalar slope gradients are sums over a whole tensor whose terms cancel; for some of them the result is so much
+    # smaller than its terms that fp32 rounding alone moves it by more than 3e-4 -- in ANY fp32 implementation.  The
+    # oracle run in fp32 measures that floor: a scalar is held to 3e-4 or three times the fp32 oracle's own deviation
+    # from float64, whichever is larger.
+    _, _, _, g32 = O.loss_and_grads(mixture, sources, sd, cfg)
     for k, p in model.named_parameters():
-        assert_close(p.grad, g64[k], 3e-4 if p.numel() == 1 else TOL, "grad " + k)
+        tol = TOL
+        if p.numel() == 1:
+            tol = max(3e-4, 3.0 * rel_err(g32[k], g64[k]))
+        assert_close(p.grad, g64[k], tol, "grad " + k)
 
 
 # (batch, Bc, H, Sc, T, dilation, causal, dual): shapes around the kernels' tile boundaries -- rows shorter than a wave,

@@ -1,10 +1,11 @@
-"""The opt-in split-bf16 arithmetic modes of the GEMMs (ctn_gemm_set_split: products on the bf16 MFMA from operands split
-into bf16 pieces, fp32 accumulation).  Two pieces / three products must keep every GEMM within 5e-5 of float64 math
-(fp32 MFMAs: 2e-5), and the bar set for this path end to end -- waveforms and loss within 1e-4 of the reference's
-outputs (golden fixtures), permutations bit-exact, training trajectories; what it loosens is documented by the bounds
-below: gradients agree with the f32-MFMA mode to 1e-3 of each tensor's largest entry (scalar PReLU-slope gradients, sums
-with heavy cancellation, to 1e-2).  Three pieces / six products represent every operand exactly and must meet the
-f32-MFMA bounds: GEMMs within 2e-5, gradients within 1e-4 (scalars 1e-3) of the f32-MFMA mode."""
+"""The arithmetic modes of the GEMMs (CTN_ARITH_* in include/ctn.h) against each other and against float64.  The default
+-- three bf16 pieces per fp32 operand, an exact representation, six products on the bf16 MFMA with fp32 accumulation --
+must meet the bounds of plain f32 MFMAs: GEMMs within 2e-5 of float64 math, gradients within 1e-4 (scalars 1e-3) of the
+f32-MFMA mode; every other GPU test of the suite runs in this default mode too.  Two pieces / three products is the opt-in
+throughput mode: every GEMM within 5e-5 of float64 math, waveforms and loss within 1e-4 of the reference's outputs (golden
+fixtures), permutations bit-exact, training trajectories; what it loosens is documented by the bounds below: gradients
+agree with the f32-MFMA mode to 1e-3 of each tensor's largest entry (scalar PReLU-slope gradients, sums with heavy
+cancellation, to 1e-2)."""
 import numpy as np
 import pytest
 import torch
@@ -17,16 +18,16 @@ from test_parity_gpu import build, load_state, dev
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[2, 3], ids=["two_pieces", "three_pieces"])
+@pytest.fixture(params=[0, 2, 3], ids=["f32_mfma", "two_pieces", "three_pieces"])
 def split_mode(request):
     from speech_amd import ops
-    assert not ops.get_gemm_split()
+    default = ops.get_gemm_split()
     ops.set_gemm_split(request.param)
     assert ops.get_gemm_split() == request.param
     try:
         yield request.param
     finally:
-        ops.set_gemm_split(0)
+        ops.set_gemm_split(default)
 
 
 def run(cfg, batch, T, seed):
@@ -85,6 +86,7 @@ def test_split_mode_gradients_close_to_f32_mode(pieces, tol_vec, tol_scalar):
             sd[k].fill_(1.0)
     mixture, sources = cases.e2e_batch(cfg, 2, 16000, 7)
     res = {}
+    default = ops.get_gemm_split()
     for mode in (False, True):
         ops.set_gemm_split(pieces if mode else 0)
         try:
@@ -95,7 +97,7 @@ def test_split_mode_gradients_close_to_f32_mode(pieces, tol_vec, tol_scalar):
             torch.cuda.synchronize()
             res[mode] = (out.detach(), loss.detach(), perm, {k: p.grad.clone() for k, p in model.named_parameters()})
         finally:
-            ops.set_gemm_split(0)
+            ops.set_gemm_split(default)
     assert torch.equal(res[True][2], res[False][2])
     assert_close(res[True][0], res[False][0], 1e-4, "waveforms")
     assert_close(res[True][1], res[False][1], 1e-4, "loss")
@@ -112,6 +114,7 @@ def test_split_mode_training_steps_track_f32_mode(pieces):
     from speech_amd.trainer import FlatTrainer
     cfg = O.CONFIG_SMALL
     traj = {}
+    default = ops.get_gemm_split()
     for mode in (False, True):
         ops.set_gemm_split(pieces if mode else 0)
         try:
@@ -123,6 +126,6 @@ def test_split_mode_training_steps_track_f32_mode(pieces):
                 loss, _ = tr.step(mixture.to(dev()), sources.to(dev()))
                 losses.append(loss.item())
         finally:
-            ops.set_gemm_split(0)
+            ops.set_gemm_split(default)
         traj[mode] = torch.tensor(losses)
     assert_close(traj[True], traj[False], 1e-3, "loss trajectory")

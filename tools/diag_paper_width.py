@@ -16,7 +16,7 @@ for name, cfg in [("e2e_paper", O.CONFIG_PAPER), ("e2e_paper_causal3", O.CONFIG_
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     batch, T = int(g["batch"]), int(g["T"])
     for width in (128, 64, 128, 64):
-        lib.ctn_gemm_nn_set_tile(width)
+        ops.set_gemm_tile(width)
         model = load_state(build(cfg), cases.e2e_state(cfg))
         mixture, sources = cases.e2e_batch(cfg, batch, T, 0)
         out = model(mixture.to(dev))

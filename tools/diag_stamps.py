@@ -7,7 +7,7 @@ import numpy as np, torch
 from speech_amd import ops, _lib
 M, K, B, W = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 lib = _lib.load()
-lib.ctn_gemm_nn_set_tile(W)
+ops.set_gemm_tile(W)
 dev = torch.device("cuda:0"); T = 3999
 A = torch.randn(K, M, device=dev); X = ops.new_act(B, K, T, dev).normal_(); Y = ops.new_act(B, M, T, dev)
 bias = torch.randn(M, device=dev)

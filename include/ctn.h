@@ -309,14 +309,14 @@ int ctn_encoder_fwd(const float* x, int64_t xbs, int Tin, int pad_left, int batc
 /* xhat[b][s][tau - trim_left] = sum_n sum_{t*S+l = tau} Wd[n][l] * w[b][n][t] * mask[b][s*N+n][t]
  * for 0 <= tau - trim_left < Tout: the mask product of conv_tasnet.py:159-160, nn.ConvTranspose1d(N, 1, L,
  * stride=S, bias=False) of filterbank.py:243-247 and the trim of conv_tasnet.py:169.  mask may be NULL
- * (plain transposed convolution of w, n_src = 1).  L <= 32. */
+ * (plain transposed convolution of w, n_src = 1).  L <= 32, stride such that (L-1)/S < 32; n_src <= 4 (<= 3 when L > 16). */
 int ctn_maskdecode_fwd(const float* w, int64_t ldw, const float* mask, int64_t ldm, int batch, int n_src,
                        int N, int Tf, const float* Wd, int L, int S, float* out, int64_t out_ss,
                        int64_t out_bs, int Tout, int trim_left, void* stream);
 
 /* Backward of ctn_maskdecode_fwd with a sigmoid mask:
  *   dwh = sum_l Wd[n][l]*dout[b][s][t*S+l-trim_left];  dz = dwh*w*m*(1-m) (sigmoid_bwd=1) or dwh*w;
- *   dw_dec[b][n][t] = sum_s dwh*m;   dWd[n][l] += sum w*m*dout.   L <= 16, n_src <= 3.
+ *   dw_dec[b][n][t] = sum_s dwh*m;   dWd[n][l] += sum w*m*dout.   L <= 32, S <= 16, n_src <= 4 (<= 3 when L > 16).
  * dz may be NULL when mask is NULL. */
 int ctn_maskdecode_bwd(const float* dout, int64_t dout_ss, int64_t dout_bs, int Tout, int trim_left,
                        const float* w, int64_t ldw, const float* mask, int64_t ldm, int batch, int n_src,
@@ -326,7 +326,7 @@ int ctn_maskdecode_bwd(const float* dout, int64_t dout_ss, int64_t dout_bs, int 
 /* Encoder backward: dwt = [relu ? (w > 0) : 1] * (dw_a + norm_bwd(dn, w)) ; dW[n][l] += sum_t dwt*xp[t*S+l];
  * dgamma[n] += sum dn*xhat ; dbeta[n] += sum dn.  dw_a may be NULL; dn and the norm arguments may be NULL
  * (no entry norm).  dwt_out (batch, N, lddwt), if not NULL, receives dwt (the gradient w.r.t. the
- * encoder's pre-activation output).  L <= 16. */
+ * encoder's pre-activation output).  L <= 32, S <= 16. */
 int ctn_encoder_bwd(const float* x, int64_t xbs, int Tin, int pad_left, int batch, int N, int L, int S, int relu,
                     const float* w, int Tf, int64_t ldw, const float* dw_a, int64_t lddwa, const float* dn,
                     int64_t lddn, const float* mean, const float* rstd, const float* c1, const float* c2,

@@ -85,9 +85,9 @@ def decoder(w_hat, weight, stride):
 # --------------------------------------------------------------------------
 # TCN: src/models/tdcn.py
 # --------------------------------------------------------------------------
-def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, eps=EPS, stride=1):
-    """ResidualBlock1d.forward (separable, prelu, norm): src/models/tdcn.py:107-147,
-    with the dual-head DepthwiseSeparableConv1d of tdcn.py:177-196 inlined."""
+def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, eps=EPS, stride=1, separable=True):
+    """ResidualBlock1d.forward (prelu, norm): src/models/tdcn.py:107-147, with the dual-head DepthwiseSeparableConv1d
+    of tdcn.py:177-196 inlined; separable=False takes the dense dilated heads of :102-105 and :136-142."""
     T = x.shape[-1]
     residual = x
     y = F.conv1d(x, sd[prefix + "bottleneck_conv1d.weight"], sd[prefix + "bottleneck_conv1d.bias"])  # :116
@@ -100,6 +100,14 @@ def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, ep
         pad_l = padding // 2
         pad_r = padding - pad_l                                                                     # :129-130
     y = F.pad(y, (pad_l, pad_r))                                                                    # :132
+    if not separable:
+        out = None
+        if dual_head:
+            out = F.conv1d(y, sd[prefix + "output_conv1d.weight"], sd[prefix + "output_conv1d.bias"],
+                           dilation=dilation) + residual                                            # :137, :145
+        skip = F.conv1d(y, sd[prefix + "skip_conv1d.weight"], sd[prefix + "skip_conv1d.bias"], dilation=dilation)  # :142
+        assert skip.shape[-1] == T
+        return out, skip
     sp = prefix + "separable_conv1d."
     H = y.shape[1]
     y = F.conv1d(y, sd[sp + "depthwise_conv1d.weight"], sd[sp + "depthwise_conv1d.bias"],
@@ -116,7 +124,7 @@ def residual_block(x, sd, prefix, dilation, causal, dual_head, kernel_size=3, ep
     return out, skip
 
 
-def tdcn(x, sd, prefix, num_blocks, num_layers, causal, kernel_size=3, eps=EPS, dilated=True):
+def tdcn(x, sd, prefix, num_blocks, num_layers, causal, kernel_size=3, eps=EPS, dilated=True, separable=True):
     """TimeDilatedConvNet.forward + TimeDilatedConvBlock1d.forward: src/models/tdcn.py:29-41, :65-75.
     Dilation 2**layer at stride 1 (:52-54), or dilation 1 at stride 2 when not dilated (:55-57); the very last layer has
     no residual head (:22-23, :58-59)."""
@@ -126,7 +134,7 @@ def tdcn(x, sd, prefix, num_blocks, num_layers, causal, kernel_size=3, eps=EPS, 
         for l in range(num_layers):
             dual = not (r == num_blocks - 1 and l == num_layers - 1)
             x, skip = residual_block(x, sd, "{}net.{}.net.{}.".format(prefix, r, l), 2 ** l if dilated else 1, causal,
-                                     dual, kernel_size, eps, stride=1 if dilated else 2)
+                                     dual, kernel_size, eps, stride=1 if dilated else 2, separable=separable)
             block_skip = block_skip + skip
         skip_total = skip_total + block_skip
     return skip_total
@@ -143,7 +151,8 @@ def separator(w, sd, cfg, prefix="separator."):
     x = layer_norm(w, sd, prefix + "norm1d.", causal, eps)                                          # :370
     x = F.conv1d(x, sd[prefix + "bottleneck_conv1d.weight"], sd[prefix + "bottleneck_conv1d.bias"])  # :371
     x = tdcn(x, sd, prefix + "tdcn.", cfg["sep_num_blocks"], cfg["sep_num_layers"], causal,
-             cfg.get("sep_kernel_size", 3), eps, dilated=cfg.get("dilated", True))                  # :372
+             cfg.get("sep_kernel_size", 3), eps, dilated=cfg.get("dilated", True),
+             separable=cfg.get("separable", True))                                                  # :372
     x = F.prelu(x, sd[prefix + "prelu.weight"])                                                     # :373
     x = F.conv1d(x, sd[prefix + "mask_conv1d.weight"], sd[prefix + "mask_conv1d.bias"])             # :374
     if cfg.get("mask_nonlinear", "sigmoid") == "sigmoid":

@@ -4,6 +4,8 @@
 // latent tensors are fully coalesced 256-byte rows, and keep the tiny L-tap basis in scalar registers
 // (the basis row of channel n is wave-uniform).  Weight gradients, which reduce over frames, go through
 // a transposed LDS tile so that a thread owns a channel and walks frames.
+#include <algorithm>
+
 #include "ctn_common.h"
 
 namespace {
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(NTH) void maskdecode_fwd_kernel(const float* __rest
 // time-domain signal, stored linearly (frame f, tap l -> F[f * S + l]; filled by coalesced loads, zero outside
 // the signal).  Thread (n_local, q) adds sum_f V[n][f] * F[f * S + l] over its quarter of the frames to acc.
 // corr_flush folds the four quarters through LDS (scratch: 4 x 64 x ML floats) and issues one atomic per (n, l).
-constexpr int FLEN = FT * 16 + 16;      // samples of one tile for stride <= 16 and <= 16 taps
+constexpr int FLEN = FT * 16 + 32;      // samples of one tile for stride <= 16 and <= 32 taps
 
 template <int ML, int NS>
 __device__ __forceinline__ void corr_accumulate(const float* V, const float* F, int S, float (&acc)[ML]) {
@@ -229,8 +231,10 @@ __global__ __launch_bounds__(NTH) void maskdecode_bwd_kernel(const float* __rest
                                                              int64_t lddz, float* __restrict__ dw_dec,
                                                              int64_t lddw, float* dWd, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* V = lds;                               // [NS][64][LDV]   (>= 4 * 64 * ML floats: also corr_flush scratch)
-    float* F = lds + (size_t)NS * FT * LDV;       // [NS][FLEN] output-gradient samples of the tile
+    // V: [NS][64][LDV] value tiles, and corr_flush's scratch of 4 * 64 * ML floats -- sized for the larger of the two
+    constexpr size_t VSZ = (size_t)NS * FT * LDV > (size_t)4 * 64 * ML ? (size_t)NS * FT * LDV : (size_t)4 * 64 * ML;
+    float* V = lds;
+    float* F = lds + VSZ;                         // [NS][FLEN] output-gradient samples of the tile
     float* Wl = F + (size_t)NS * FLEN;            // [64][ML] basis rows of this block's channels, zero-padded
     const int b = blockIdx.z, n0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -318,7 +322,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                                                           const float* __restrict__ gamma, float* dW,
                                                           float* dgamma, float* dbeta, float* dwt_out,
                                                           int64_t lddwt, int tiles_per_block) {
-    __shared__ float V[FT * LDV];                 // 64 x 65 >= 4 * 64 * ML floats: also corr_flush scratch
+    // 64 x 65 value tile, and corr_flush's scratch of 4 * 64 * ML floats -- sized for the larger of the two
+    __shared__ float V[FT * LDV > 4 * 64 * ML ? FT * LDV : 4 * 64 * ML];
     __shared__ float F[FLEN];
     const int b = blockIdx.z, n0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -439,7 +444,7 @@ int ctn_maskdecode_fwd(const float* w, int64_t ldw, const float* mask, int64_t l
     CTN_REQUIRE(ldw >= Tf && (!mask || ldm >= Tf), "ctn_maskdecode_fwd: ld < Tf");
     const int R1 = (L - 1) / S;
     CTN_REQUIRE(R1 < FT / 2, "ctn_maskdecode_fwd: kernel_size / stride too large");
-    CTN_REQUIRE(n_src <= 3, "ctn_maskdecode_fwd: n_src <= 3");
+    CTN_REQUIRE(n_src <= (L <= 16 ? 4 : 3), "ctn_maskdecode_fwd: n_src <= 4 (<= 3 for more than 16 taps)");
     const int TTo = FT - R1;
     dim3 grid(ctn_cdiv(Tf, TTo), batch);
     hipStream_t s = (hipStream_t)stream;
@@ -461,7 +466,8 @@ int ctn_maskdecode_fwd(const float* w, int64_t ldw, const float* mask, int64_t l
     } while (0)
         if (n_src == 1) CTN_MDF(16, 1);
         else if (n_src == 2) CTN_MDF(16, 2);
-        else CTN_MDF(16, 3);
+        else if (n_src == 3) CTN_MDF(16, 3);
+        else CTN_MDF(16, 4);
     } else {
         if (n_src == 1) CTN_MDF(32, 1);
         else if (n_src == 2) CTN_MDF(32, 2);
@@ -477,9 +483,9 @@ int ctn_maskdecode_bwd(const float* dout, int64_t dout_ss, int64_t dout_bs, int 
                        int64_t ldw, const float* mask, int64_t ldm, int batch, int n_src, int N, int Tf,
                        const float* Wd, int L, int S, int sigmoid_bwd, float* dz, int64_t lddz, float* dw_dec,
                        int64_t lddw, float* dWd, void* stream) {
-    CTN_REQUIRE(dout && w && Wd && dWd && batch > 0 && n_src >= 1 && n_src <= 3 && N > 0 && Tf > 0 && L > 0 &&
-                    L <= 16 && S > 0,
-                "ctn_maskdecode_bwd: bad arguments (L <= 16, n_src <= 3)");
+    CTN_REQUIRE(dout && w && Wd && dWd && batch > 0 && n_src >= 1 && N > 0 && Tf > 0 && L > 0 && L <= 32 && S > 0,
+                "ctn_maskdecode_bwd: bad arguments (L <= 32)");
+    CTN_REQUIRE(n_src <= (L <= 16 ? 4 : 3), "ctn_maskdecode_bwd: n_src <= 4 (<= 3 for more than 16 taps)");
     CTN_REQUIRE(ldw >= Tf && (!mask || ldm >= Tf) && (!dz || lddz >= Tf) && (!dw_dec || lddw >= Tf),
                 "ctn_maskdecode_bwd: ld < Tf");
     CTN_REQUIRE(!mask || dz, "ctn_maskdecode_bwd: dz required with a mask");
@@ -488,16 +494,28 @@ int ctn_maskdecode_bwd(const float* dout, int64_t dout_ss, int64_t dout_bs, int 
     const int tpb = tiles_per_block(ntiles, ctn_cdiv(N, 64) * batch);
     dim3 grid(ctn_cdiv(ntiles, tpb), ctn_cdiv(N, 64), batch);
     hipStream_t s = (hipStream_t)stream;
-    const size_t shmem = ((size_t)n_src * FT * LDV + (size_t)n_src * FLEN + 64 * 16) * sizeof(float);
-#define CTN_MD_LAUNCH(NS, MK)                                                                                       \
-    hipLaunchKernelGGL((maskdecode_bwd_kernel<16, NS, MK>), grid, dim3(NTH), shmem, s, dout, dout_ss, dout_bs, Tout,   \
-                       trim_left, w, ldw, mask, ldm, N, Tf, Wd, L, S, sigmoid_bwd, dz, lddz, dw_dec, lddw, dWd, tpb)
-#define CTN_MD_CASE(NS)                      \
-    case NS:                                 \
-        if (mask) CTN_MD_LAUNCH(NS, true);   \
-        else CTN_MD_LAUNCH(NS, false);       \
+    const int ML = L <= 16 ? 16 : 32;
+    const size_t vsz = std::max((size_t)n_src * FT * LDV, (size_t)4 * 64 * ML);
+    const size_t shmem = (vsz + (size_t)n_src * FLEN + (size_t)64 * ML) * sizeof(float);
+#define CTN_MD_LAUNCH(MLV, NS, MK)                                                                                  \
+    do {                                                                                                            \
+        if (shmem > 48 * 1024)                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&maskdecode_bwd_kernel<MLV, NS, MK>),           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                      \
+        hipLaunchKernelGGL((maskdecode_bwd_kernel<MLV, NS, MK>), grid, dim3(NTH), shmem, s, dout, dout_ss, dout_bs,   \
+                           Tout, trim_left, w, ldw, mask, ldm, N, Tf, Wd, L, S, sigmoid_bwd, dz, lddz, dw_dec, lddw,  \
+                           dWd, tpb);                                                                               \
+    } while (0)
+#define CTN_MD_CASE(MLV, NS)                      \
+    case NS:                                      \
+        if (mask) CTN_MD_LAUNCH(MLV, NS, true);   \
+        else CTN_MD_LAUNCH(MLV, NS, false);       \
         break;
-    switch (n_src) { CTN_MD_CASE(1) CTN_MD_CASE(2) CTN_MD_CASE(3) }
+    if (ML == 16) {
+        switch (n_src) { CTN_MD_CASE(16, 1) CTN_MD_CASE(16, 2) CTN_MD_CASE(16, 3) CTN_MD_CASE(16, 4) }
+    } else {
+        switch (n_src) { CTN_MD_CASE(32, 1) CTN_MD_CASE(32, 2) CTN_MD_CASE(32, 3) }
+    }
 #undef CTN_MD_CASE
 #undef CTN_MD_LAUNCH
     CTN_CHECK_LAUNCH("ctn_maskdecode_bwd");
@@ -509,8 +527,8 @@ int ctn_encoder_bwd(const float* x, int64_t xbs, int Tin, int pad_left, int batc
                     int64_t lddn, const float* mean, const float* rstd, const float* c1, const float* c2, int64_t ssb,
                     int64_t sst, const float* gamma, float* dW, float* dgamma, float* dbeta, float* dwt_out,
                     int64_t lddwt, void* stream) {
-    CTN_REQUIRE(x && w && dW && batch > 0 && N > 0 && L > 0 && L <= 16 && S > 0 && Tf > 0 && Tin > 0,
-                "ctn_encoder_bwd: bad arguments (L <= 16)");
+    CTN_REQUIRE(x && w && dW && batch > 0 && N > 0 && L > 0 && L <= 32 && S > 0 && Tf > 0 && Tin > 0,
+                "ctn_encoder_bwd: bad arguments (L <= 32)");
     CTN_REQUIRE(ldw >= Tf && (!dw_a || lddwa >= Tf) && (!dn || lddn >= Tf) && (!dwt_out || lddwt >= Tf),
                 "ctn_encoder_bwd: ld < Tf");
     CTN_REQUIRE(dw_a || dn, "ctn_encoder_bwd: no incoming gradient");
@@ -519,13 +537,19 @@ int ctn_encoder_bwd(const float* x, int64_t xbs, int Tin, int pad_left, int batc
     const int ntiles = ctn_cdiv(Tf, FT);
     const int tpb = tiles_per_block(ntiles, ctn_cdiv(N, 64) * batch);
     dim3 grid(ctn_cdiv(ntiles, tpb), ctn_cdiv(N, 64), batch);
-#define CTN_EB(DA, DN)                                                                                            \
-    hipLaunchKernelGGL((encoder_bwd_kernel<16, DA, DN>), grid, dim3(NTH), 0, (hipStream_t)stream, x, xbs, Tin,        \
+#define CTN_EB_(MLV, DA, DN)                                                                                      \
+    hipLaunchKernelGGL((encoder_bwd_kernel<MLV, DA, DN>), grid, dim3(NTH), 0, (hipStream_t)stream, x, xbs, Tin,       \
                        pad_left, N, L, S, relu, w, Tf, ldw, dw_a, lddwa, dn, lddn, mean, rstd, c1, c2, ssb, sst, gamma, \
                        dW, dgamma, dbeta, dwt_out, lddwt, tpb)
+#define CTN_EB(DA, DN)                  \
+    do {                                \
+        if (L <= 16) CTN_EB_(16, DA, DN); \
+        else CTN_EB_(32, DA, DN);         \
+    } while (0)
     if (dw_a && dn) CTN_EB(true, true);
     else if (dw_a) CTN_EB(true, false);
     else CTN_EB(false, true);
+#undef CTN_EB_
 #undef CTN_EB
     CTN_CHECK_LAUNCH("ctn_encoder_bwd");
     return CTN_OK;

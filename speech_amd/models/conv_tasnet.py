@@ -80,7 +80,8 @@ class ConvTasNet(nn.Module):
     def _fused_ok(self):
         return (self.enc_basis == 'trainable' and self.dec_basis in ('trainable', 'pinv') and self.in_channels == 1
                 and self.dilated and self.separable and self.sep_nonlinear == 'prelu' and self.sep_norm
-                and self.mask_nonlinear == 'sigmoid' and self.kernel_size <= 16 and self.n_sources <= 3)
+                and self.mask_nonlinear == 'sigmoid' and self.kernel_size <= 32 and self.stride <= 16
+                and (self.kernel_size - 1) // self.stride < 32 and self.n_sources <= (4 if self.kernel_size <= 16 else 3))
 
     def fused_config(self):
         return dict(n_basis=self.n_basis, kernel_size=self.kernel_size, stride=self.stride,
@@ -235,8 +236,8 @@ class Separator(nn.Module):
         self.num_features, self.n_sources = num_features, n_sources
         self.num_blocks, self.num_layers = num_blocks, num_layers
         self.causal, self.eps = causal, eps
-        self.hip_ok = separable and nonlinear == 'prelu' and norm
-        self.dilated = dilated
+        self.hip_ok = nonlinear == 'prelu' and norm
+        self.dilated, self.separable = dilated, separable
 
         norm_name = 'cLN' if causal else 'gLN'
         self.norm1d = choose_layer_norm(norm_name, num_features, causal=causal, eps=eps)
@@ -271,11 +272,12 @@ class Separator(nn.Module):
             output (batch_size, n_sources, n_basis, n_frames)
         """
         if not self.hip_ok:
-            raise NotImplementedError("HIP path: Separator needs separable, prelu and norm")
+            raise NotImplementedError("HIP path: Separator needs prelu and norm")
         num_features, n_sources = self.num_features, self.n_sources
         batch_size, _, n_frames = input.size()
-        if not self.dilated:
-            # stride-2 layers (src/models/tdcn.py:55-57): module by module, conv_tasnet.py:360-376
+        if not self.dilated or not self.separable:
+            # stride-2 layers (src/models/tdcn.py:55-57) or dense dilated heads (:102-105): module by module,
+            # conv_tasnet.py:360-376
             g0, be0 = _norm_params(self.norm1d)
             x = LayerNormFn.apply(input, g0, be0, self.eps, self.causal)
             x = Conv1x1Fn.apply(x, self.bottleneck_conv1d.weight, self.bottleneck_conv1d.bias)

@@ -101,11 +101,26 @@ class ResidualBlock1d(nn.Module):
                 hidden_channels, num_features, skip_channels=skip_channels, kernel_size=kernel_size, stride=stride,
                 dilation=dilation, causal=causal, nonlinear=nonlinear, norm=norm, dual_head=dual_head, eps=eps)
         else:
-            raise NotImplementedError("HIP path: separable=True only (dense dilated convolutions are not on "
-                                      "the Conv-TasNet hot path)")
+            # dense dilated heads (src/models/tdcn.py:102-105): these modules hold the parameters under the reference's
+            # names; forward() runs every tap as a pointwise GEMM over a shifted view of the padded input
+            if dual_head:
+                self.output_conv1d = nn.Conv1d(hidden_channels, num_features, kernel_size=kernel_size, dilation=dilation)
+            self.skip_conv1d = nn.Conv1d(hidden_channels, skip_channels, kernel_size=kernel_size, dilation=dilation)
 
     def hip_supported(self):
         return self.separable and self.nonlinear and self.norm and self.stride == 1
+
+    @staticmethod
+    def _dense_dilated(x_padded, conv, T_out):
+        """nn.Conv1d(C_in, C_out, P, dilation=d) on an already padded input as P pointwise convolutions of shifted
+        views, summed: y = b + sum_k W[:, :, k] . x[:, :, k d : k d + T_out] -- each a ctn_gemm_nn / ctn_gemm_nt pair."""
+        P, d = conv.kernel_size[0], conv.dilation[0]
+        y = None
+        for k in range(P):
+            tap = Conv1x1Fn.apply(x_padded[:, :, k * d:k * d + T_out], conv.weight[:, :, k:k + 1].contiguous(),
+                                  conv.bias if k == 0 else None)
+            y = tap if y is None else y + tap
+        return y
 
     def parameter_list(self):
         """Parameters in the order speech_amd.functional.Layer expects."""
@@ -124,8 +139,12 @@ class ResidualBlock1d(nn.Module):
             output, skip = ResidualBlockFn.apply(input, self.dilation, self.causal, self.dual_head, self.eps,
                                                  *self.parameter_list())
             return output, skip
-        if not (self.separable and self.nonlinear and self.norm):
-            raise NotImplementedError("HIP path: ResidualBlock1d needs separable, prelu and norm")
+        if not (self.nonlinear and self.norm):
+            raise NotImplementedError("HIP path: ResidualBlock1d needs prelu and norm")
+        if not self.separable and self.stride != 1:
+            # the reference's dense heads take no stride (src/models/tdcn.py:103-105) while its padding assumes one
+            # (:123): with stride 2 its own output no longer matches the residual in length
+            raise NotImplementedError("non-separable residual layers exist for stride 1 (dilated=True) only")
         # strided (non-dilated) layers, src/models/tdcn.py:55-57: stage by stage on the same kernels; the padding keeps
         # the frame count (:123-132), so most of what the stride-2 depthwise convolution reads is zero padding
         kernel_size, stride, dilation = self.kernel_size, self.stride, self.dilation
@@ -138,7 +157,11 @@ class ResidualBlock1d(nn.Module):
         padding = (T_original - 1) * stride - T_original + (kernel_size - 1) * dilation + 1
         padding_left = padding if self.causal else padding // 2
         x = F.pad(x, (padding_left, padding - padding_left))
-        output, skip = self.separable_conv1d(x)
+        if self.separable:
+            output, skip = self.separable_conv1d(x)
+        else:                                          # src/models/tdcn.py:136-142
+            output = self._dense_dilated(x, self.output_conv1d, T_original) if self.dual_head else None
+            skip = self._dense_dilated(x, self.skip_conv1d, T_original)
         if output is not None:
             output = output + input
         return output, skip

@@ -36,6 +36,13 @@ E2E = {
     "fourier_pinv": dict(enc_basis="trainableFourier", dec_basis="pinv", enc_onesided=False, enc_return_complex=False,
                          window_fn="hann"),
 }
+# dense dilated heads instead of the depthwise-separable convolution (src/models/tdcn.py:102-105, :136-142);
+# fixture tests/golden/nonseparable.npz, written by tools/gen_golden_nonseparable.py
+E2E_NONSEPARABLE = {
+    "nonseparable": dict(enc_basis="trainable", dec_basis="trainable", separable=False, sep_num_layers=3),
+    "nonseparable_causal": dict(enc_basis="trainable", dec_basis="trainable", separable=False, causal=True, n_sources=3,
+                                enc_nonlinear="relu", sep_num_blocks=2),
+}
 FOURIER_LEAVES = ("frequency", "time_seq", "window", "optimal_window", "phase")
 
 

@@ -89,10 +89,10 @@ def test_pinv_and_gated(golden):
     assert check(g, "gated", out, p, [x]) == 2
 
 
-@pytest.mark.parametrize("key", list(FC.E2E))
+@pytest.mark.parametrize("key", list(FC.E2E) + list(FC.E2E_NONSEPARABLE))
 def test_conv_tasnet_with_filterbank_variants(golden, key):
-    g = golden("filterbank")
-    cfg = dict(FC.E2E_BASE, **FC.E2E[key])
+    g = golden("nonseparable" if key in FC.E2E_NONSEPARABLE else "filterbank")
+    cfg = dict(FC.E2E_BASE, **(FC.E2E_NONSEPARABLE[key] if key in FC.E2E_NONSEPARABLE else FC.E2E[key]))
     sd = params(g, "e2e_" + key)
     mixture, sources = FC.e2e_batch(synth, cfg)
     out = FO.conv_tasnet_forward(mixture, sd, cfg)

@@ -115,13 +115,13 @@ def test_gated_encoder(golden):
     assert check(g, "gated", m, m(x), [x]) == 2
 
 
-@pytest.mark.parametrize("key", list(FC.E2E))
+@pytest.mark.parametrize("key", list(FC.E2E) + list(FC.E2E_NONSEPARABLE))
 def test_conv_tasnet_with_filterbank_variants(golden, key):
     from speech_amd.criterion.pit import PIT1d
     from speech_amd.criterion.sdr import NegSISDR
     from speech_amd.models.conv_tasnet import ConvTasNet
-    g = golden("filterbank")
-    cfg = dict(FC.E2E_BASE, **FC.E2E[key])
+    g = golden("nonseparable" if key in FC.E2E_NONSEPARABLE else "filterbank")
+    cfg = dict(FC.E2E_BASE, **(FC.E2E_NONSEPARABLE[key] if key in FC.E2E_NONSEPARABLE else FC.E2E[key]))
     model = ConvTasNet(cfg["n_basis"], cfg["kernel_size"], stride=cfg["stride"], enc_basis=cfg["enc_basis"],
                        dec_basis=cfg["dec_basis"], enc_nonlinear=cfg.get("enc_nonlinear"),
                        in_channels=cfg.get("in_channels") or 1, window_fn=cfg.get("window_fn"),
@@ -129,8 +129,8 @@ def test_conv_tasnet_with_filterbank_variants(golden, key):
                        sep_hidden_channels=cfg["sep_hidden_channels"], sep_bottleneck_channels=cfg["sep_bottleneck_channels"],
                        sep_skip_channels=cfg["sep_skip_channels"], sep_kernel_size=cfg["sep_kernel_size"],
                        sep_num_blocks=cfg["sep_num_blocks"], sep_num_layers=cfg["sep_num_layers"], dilated=cfg.get("dilated", True),
-                       separable=True, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear=cfg["mask_nonlinear"],
-                       causal=cfg["causal"], n_sources=cfg["n_sources"])
+                       separable=cfg.get("separable", True), sep_nonlinear="prelu", sep_norm=True,
+                       mask_nonlinear=cfg["mask_nonlinear"], causal=cfg["causal"], n_sources=cfg["n_sources"])
     assert list(model.state_dict().keys()) == [str(k) for k in g["e2e_" + key + "_keys"]]
     load(model, g, "e2e_" + key)
     mixture, sources = FC.e2e_batch(synth, cfg)

@@ -370,7 +370,9 @@ def test_depthwise_backward_recomputed_output_matches_stored(d, pad_left, T):
                                         (16, 8, 16, False),       # one frame
                                         (16, 16, 4096, True),     # no overlap between frames
                                         (10, 5, 1005, False),     # taps and stride that are not powers of two
-                                        (3, 1, 77, True), (8, 2, 64001, False), (2, 1, 64000, False)])
+                                        (3, 1, 77, True), (8, 2, 64001, False), (2, 1, 64000, False),
+                                        (20, 10, 4410, False),    # more than 16 taps (the 44.1 kHz music recipes use L = 20)
+                                        (32, 16, 2048, True), (24, 6, 999, False), (17, 1, 300, True)])
 def test_encoder_decoder(L, S, T, relu):
     import convtasnet_oracle as O
     from speech_amd.functional import EncoderFn, DecoderFn

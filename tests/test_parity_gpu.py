@@ -362,13 +362,19 @@ def test_paper_backward_is_reproducible():
     ("small", 1, 80000),      # 10 s: 9999 frames, rows longer than the one-block depthwise backward handles
     ("small_causal3", 2, 1001),
     ("small_causal3", 1, 40000),
+    ("small_L20", 2, 4410),   # 20-tap basis, hop 10: beyond the 16 taps of the paper configuration, through the fused schedule
+    ("small_L32_3src", 1, 3000),
+    ("small_4src", 2, 1001),  # four sources through the fused schedule
 ])
 def test_ragged_minimal_and_long_inputs_vs_float64(cfg_name, batch, T):
     """Shapes the fixtures do not hold, against a float64 run of the oracle on the kink-free network (PReLU slopes 1),
     so waveforms, loss and every gradient are held to the strict bar."""
     from speech_amd.criterion.pit import PIT1d
     from speech_amd.criterion.sdr import NegSISDR
-    cfg = O.CONFIG_SMALL if cfg_name == "small" else dict(O.CONFIG_SMALL, causal=True, n_sources=3)
+    cfg = {"small": O.CONFIG_SMALL, "small_causal3": dict(O.CONFIG_SMALL, causal=True, n_sources=3),
+           "small_L20": dict(O.CONFIG_SMALL, kernel_size=20, stride=10),
+           "small_L32_3src": dict(O.CONFIG_SMALL, kernel_size=32, stride=16, n_sources=3),
+           "small_4src": dict(O.CONFIG_SMALL, n_sources=4)}[cfg_name]
     sd = cases.e2e_state(cfg)
     for k in sd:
         if k.endswith("nonlinear1d.weight") or k.endswith("prelu.weight"):
@@ -377,6 +383,7 @@ def test_ragged_minimal_and_long_inputs_vs_float64(cfg_name, batch, T):
     loss64, perm64, out64, g64 = O.loss_and_grads(mixture.double(), sources.double(), {k: v.double() for k, v in sd.items()},
                                                   cfg)
     model = load_state(build(cfg), sd)
+    assert model._fused_ok()                       # these shapes are served by the fused schedule, not module by module
     out = model(mixture.to(dev()))
     assert tuple(out.shape) == (batch, cfg["n_sources"], T)
     loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))
@@ -460,8 +467,7 @@ def test_resblock_shape_sweep_vs_float64(case, smooth):
 
 @pytest.mark.parametrize("variant", ["softmax_mask", "four_sources", "input_4d"])
 def test_modular_path_variants_vs_float64(variant):
-    """Configurations the fused schedule does not take and the module-by-module path serves (same kernels, one autograd
-    node per module): the softmax mask -- over all n_sources * N channels jointly, as src/models/conv_tasnet.py:346,375
+    """Configurations served by the module-by-module path (same kernels, one autograd node per module): the softmax mask -- over all n_sources * N channels jointly, as src/models/conv_tasnet.py:346,375
     applies it -- four sources, and the 4-D input form (B, 1, n_mics = 1, T) of conv_tasnet.py:138-141; kink-free
     slopes, strict bar."""
     from speech_amd.criterion.pit import PIT1d
@@ -479,12 +485,14 @@ def test_modular_path_variants_vs_float64(variant):
     loss64, perm64, out64, g64 = O.loss_and_grads(mixture.double(), sources.double(), {k: v.double() for k, v in sd.items()},
                                                   cfg)
     model = load_state(build(cfg), sd)
-    assert model._fused_ok() == (variant == "input_4d")
+    assert model._fused_ok() == (variant != "softmax_mask")
     x = mixture.to(dev())
     if variant == "input_4d":
         out = model(x.unsqueeze(2))
         assert tuple(out.shape) == (2, cfg["n_sources"], 1, 4001)
         out = out.squeeze(2)
+    elif variant == "four_sources":        # the fused schedule takes four sources too (the ragged-shape test runs it);
+        out, _ = model.extract_latent(x)   # here they go module by module
     else:
         out = model(x)
     loss, perm = PIT1d(NegSISDR(), cfg["n_sources"])(out, sources.to(dev()))

@@ -45,7 +45,7 @@ def timeit(fn, d, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for d in (1, 2, 4, 8, 16, 32, 64, 128):
+for d in [int(v) for v in os.environ.get("DW_DILS", "1,2,4,8,16,32,64,128").split(",")]:
     tf, tb = timeit(fwd, d), timeit(bwd, d)
     print("d=%3d  fwd %6.1f us %6.0f GB/s (2E)   bwd %6.1f us  %6.0f GB/s (3E) %6.0f GB/s (4E)" % (
         d, tf, 2 * E / tf / 1e3, tb, 3 * E / tb / 1e3, 4 * E / tb / 1e3), flush=True)

@@ -10,16 +10,16 @@ OUT=$REPO/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eager -o eager -- \
-    python3 $REPO/bench.py --steps 10 --warmup 2 --streams 1 --no-graph --no-cpu-baseline --no-split-probe > $OUT/eager_line.json 2> $OUT/eager.err
+    python3 $REPO/bench.py --steps 10 --warmup 2 --streams 1 --no-graph --no-cpu-baseline --no-split-probe --no-recipe-batch > $OUT/eager_line.json 2> $OUT/eager.err
 echo "pass 1 done"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default -o default -- \
-    python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-split-probe > $OUT/default_line.json 2> $OUT/default.err
+    python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-split-probe --no-recipe-batch > $OUT/default_line.json 2> $OUT/default.err
 echo "pass 2 done"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- \
-    python3 $REPO/bench.py --steps 1 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --no-split-probe --no-roofline > $OUT/fetch_line.json 2> $OUT/fetch.err
+    python3 $REPO/bench.py --steps 1 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --no-split-probe --no-recipe-batch --no-roofline > $OUT/fetch_line.json 2> $OUT/fetch.err
 echo "pass 3 done"
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- \
-    python3 $REPO/bench.py --steps 1 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --no-split-probe --no-roofline > $OUT/write_line.json 2> $OUT/write.err
+    python3 $REPO/bench.py --steps 1 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --no-split-probe --no-recipe-batch --no-roofline > $OUT/write_line.json 2> $OUT/write.err
 echo "pass 4 done"
 cd $REPO
 F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1)

@@ -116,6 +116,24 @@ int ctn_overlap_add(const float* y, int batch, int C, int S, int K, int P, int p
                     int64_t ldx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LSTM recurrence over whole sequences in one launch: the nn.LSTM(batch_first=True) of the dual-path blocks
+ * (src/models/dprnn.py:60,85 inside chunks, :104-114,137 across chunks; gate order i, f, g, o as in torch), one or two
+ * directions, zero initial state.  The caller hoists the input projection out of the recurrence:
+ *   xproj  (N, T, D, 4H)  W_ih x_t + b_ih + b_hh for every sequence n, step t, direction d (one GEMM)
+ *   whh    (D, 4H, H)     recurrent weights as torch stores them (weight_hh_l0, weight_hh_l0_reverse)
+ *   hout   (N, T, D, H)   h_t; direction 1 walks t = T-1 .. 0 and stores its state at the step it has just consumed
+ *   save   (N, T, D, 5, H) i, f, g, o after their non-linearities and the cell state c_t, for ctn_lstm_bwd
+ * ctn_lstm_bwd walks the steps in the opposite order: from dhout (N, T, D, H) = dL/dh_t and `save` it writes
+ *   dgates (N, T, D, 4H)  dL/d(gate pre-activations) = dL/dxproj,
+ * from which the weight, bias and input gradients are plain GEMMs / sums over (N, T).
+ * H <= 128 and H % 4 == 0; all tensors dense and 16-byte aligned; fp32 throughout (f32 MFMA).
+ * ------------------------------------------------------------------------------------------- */
+int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int D, float* hout, float* save,
+                 void* stream);
+int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N, int T, int H, int D, float* dgates,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Pointwise (1x1) convolution as a batched GEMM on f32 MFMA:  Y[b] = A^T-layout(W) . xform(X[b])
  * Replaces nn.Conv1d(kernel_size=1) at src/models/conv_tasnet.py:335,341 (:371,:374) and
  * src/models/tdcn.py:86,173,175 (:116,:190,:194), forward and input-gradient, with the PReLU /

@@ -1,0 +1,306 @@
+// Persistent LSTM recurrence kernels (forward and backward through time), gfx950.
+//
+// The dual-path RNN blocks run an LSTM over hundreds of time steps on thousands of short, independent sequences
+// (src/models/dprnn.py:51-148: hidden size 128, 250 steps x ~2000 sequences inside chunks, ~500 steps x 1000 sequences
+// across chunks).  A library LSTM launches a small GEMM and a pointwise kernel per time step -- some 30 000 launches per
+// training step at the recipe's defaults.  Here ONE launch walks all time steps:
+//
+//   * the part of a step that does not depend on the previous step -- W_ih x_t + b_ih + b_hh for every t -- is hoisted
+//     out as one large GEMM by the caller (`xproj`);
+//   * a workgroup owns 16 sequences of one direction and keeps them for the whole walk; its four waves split the hidden
+//     units (wave w: units [HP/4 w, HP/4 (w+1)), all four gates of each), and every wave holds ITS rows of the recurrent
+//     matrix W_hh in registers for the whole kernel as MFMA A-fragments (hidden size 128: 256 registers per lane -- the
+//     kernel runs one wave per SIMD on purpose);
+//   * per step: h_{t-1} (16 columns, from LDS) is the B operand of v_mfma_f32_16x16x4_f32, the accumulators start from
+//     xproj_t (prefetched one step ahead), and the accumulator layout -- four consecutive hidden units of one sequence
+//     per lane, the same in all four gate tiles -- lets the cell update c = f c + i g, h = o tanh(c) run in registers;
+//     h_t goes to LDS for the next step and, with the gate values the backward pass needs, to HBM as 16-byte stores.
+//   * one barrier per step (forward), two (backward: the gate gradients go through LDS to become the B operand of
+//     W_hh^T).
+// Exact fp32 arithmetic (f32 MFMA), so the recurrence accumulates no error beyond fp32 rounding over hundreds of steps.
+//
+// Hidden sizes up to 128 (multiple of 4) are padded to HP = 64 or 128 with zero weights: padded units stay at
+// c = h = 0 and are never stored.
+#include "ctn_common.h"
+
+namespace {
+
+constexpr int NTH = 256;
+constexpr int NSEQ = 16;                  // sequences per workgroup = the N of the 16x16x4 MFMA
+
+// Gate non-linearities on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: about 1 ulp each).  A step of
+// the recurrence evaluates 40 of them per lane on its critical path -- nothing else runs on a SIMD that holds one wave --
+// and the library versions cost about four times as many instructions.  Absolute error below 3e-7, far inside the fp32
+// noise the recurrence carries anyway (the kernel tests hold h and every gradient to 2e-5 / 5e-5 of float64).
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {          // 2 sigmoid(2x) - 1
+    return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.f);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+// NT: 16-unit tiles per gate and wave (HP = 64 NT padded hidden units)
+template <int NT>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_kernel(
+    const float* __restrict__ xproj, const float* __restrict__ whh, float* __restrict__ hout, float* __restrict__ save,
+    const int N, const int T, const int H, const int D) {
+    constexpr int HP = 64 * NT, KS = HP / 4, UPW = 16 * NT;          // padded units, k-steps, units per wave
+    __shared__ float hbuf[2][HP * NSEQ];                               // h_{t-1}: [unit][sequence], double-buffered
+    const int dir = blockIdx.y, n0 = blockIdx.x * NSEQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, rg = lane >> 4;
+    const int n = n0 + col;
+    const bool nv = n < N;
+    const int nc = min(n, N - 1);
+    const float* W = whh + (size_t)dir * 4 * H * H;
+
+    // A fragments of this wave's gate rows: tile (gate g, sub-tile s), k-step kk: A[m = lane & 15][k = 4 kk + (lane >> 4)]
+    float wreg[4][NT][KS];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int u = wave * UPW + 16 * s + (lane & 15), k = 4 * kk + rg;
+                wreg[g][s][kk] = (u < H && k < H) ? W[((size_t)g * H + u) * H + k] : 0.f;
+            }
+    // this lane's units of sub-tile s: ub[s] .. ub[s] + 3 (C/D layout: row = 4 (lane >> 4) + reg, column = lane & 15)
+    int ub[NT];
+    bool uv[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        ub[s] = wave * UPW + 16 * s + 4 * rg;
+        uv[s] = ub[s] < H;                                            // H % 4 == 0: the four units are valid together
+    }
+    float c[NT][4];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[s][e] = 0.f;
+    for (int i = tid; i < HP * NSEQ; i += NTH) hbuf[0][i] = 0.f;
+
+    const int64_t row_x = (int64_t)D * 4 * H;                          // floats per (sequence, step) of xproj
+    auto load_x = [&](int t, f32x4 (&xp)[4][NT]) {
+        const float* base = xproj + ((int64_t)nc * T + t) * row_x + (int64_t)dir * 4 * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                const f32x4 v = ctn_ld4(base + g * H + (uv[s] ? ub[s] : 0));      // clamped address, masked value
+                xp[g][s] = uv[s] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
+    f32x4 xp[4][NT];
+    load_x(dir == 0 ? 0 : T - 1, xp);
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[g][s] = xp[g][s];
+        if (step + 1 < T) load_x(dir == 0 ? t + 1 : t - 1, xp);       // in flight during this step's MFMAs
+        const float* hb = hbuf[step & 1];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const float b = hb[(4 * kk + rg) * NSEQ + col];            // B[k = 4 kk + (lane >> 4)][n = lane & 15]
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int s = 0; s < NT; ++s)
+                    acc[g][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g][s][kk], b, acc[g][s], 0, 0, 0);
+        }
+        float* hn = hbuf[(step + 1) & 1];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            f32x4 iv, fv, gv, ov, cv, hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#ifndef CTN_DBG_LSTM_NOPOINT
+                iv[e] = sigmoidf_(acc[0][s][e]);
+                fv[e] = sigmoidf_(acc[1][s][e]);
+                gv[e] = tanhf_(acc[2][s][e]);
+                ov[e] = sigmoidf_(acc[3][s][e]);
+                c[s][e] = fv[e] * c[s][e] + iv[e] * gv[e];
+                cv[e] = c[s][e];
+                hv[e] = ov[e] * tanhf_(c[s][e]);
+#else
+                iv[e] = acc[0][s][e]; fv[e] = acc[1][s][e]; gv[e] = acc[2][s][e]; ov[e] = acc[3][s][e];
+                c[s][e] = fv[e] * c[s][e] + iv[e] * gv[e];
+                cv[e] = c[s][e];
+                hv[e] = ov[e] * 0.001f;
+#endif
+                hn[(ub[s] + e) * NSEQ + col] = hv[e];
+            }
+#ifndef CTN_DBG_LSTM_NOSTORE
+            if (nv && uv[s]) {
+#else
+            if (nv && uv[s] && t == 12345678) {
+#endif
+                const int64_t o = ((int64_t)n * T + t) * D + dir;
+                ctn_st4(hout + o * H + ub[s], hv);
+                float* sv = save + o * 5 * H + ub[s];
+                ctn_st4(sv, iv);
+                ctn_st4(sv + H, fv);
+                ctn_st4(sv + 2 * H, gv);
+                ctn_st4(sv + 3 * H, ov);
+                ctn_st4(sv + 4 * H, cv);
+            }
+        }
+        __syncthreads();              // h_t complete in hn; every wave is done reading hb
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward through time
+template <int NT>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(
+    const float* __restrict__ dhout, const float* __restrict__ save, const float* __restrict__ whh,
+    float* __restrict__ dgates, const int N, const int T, const int H, const int D) {
+    constexpr int HP = 64 * NT, ROWS = 4 * HP, KS = ROWS / 4, UPW = 16 * NT;
+    __shared__ float dgbuf[ROWS * NSEQ];                               // gate gradients of this step: [padded row][sequence]
+    const int dir = blockIdx.y, n0 = blockIdx.x * NSEQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, rg = lane >> 4;
+    const int n = n0 + col;
+    const bool nv = n < N;
+    const int nc = min(n, N - 1);
+    const float* W = whh + (size_t)dir * 4 * H * H;
+
+    // A fragments of W_hh^T for this wave's output units: A[m = unit][k = padded gate row g HP + u']
+    float wt[NT][KS];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int u = wave * UPW + 16 * s + (lane & 15);
+            const int r = 4 * kk + rg, g = r / HP, ur = r % HP;
+            wt[s][kk] = (u < H && ur < H) ? W[((size_t)g * H + ur) * H + u] : 0.f;
+        }
+    int ub[NT];
+    bool uv[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        ub[s] = wave * UPW + 16 * s + 4 * rg;
+        uv[s] = ub[s] < H;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dh_rec[NT], dc_carry[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) dh_rec[s] = dc_carry[s] = zero4;
+
+    // what one step reads: the five saved tensors at t, the cell state of the step before t in forward order, dL/dh_t
+    struct StepIn {
+        f32x4 sv[5][NT], cp[NT], dho[NT];
+    };
+    auto load_step = [&](int t, StepIn& in) {
+        const int tp = dir == 0 ? t - 1 : t + 1;                       // forward-order predecessor
+        const bool has_prev = tp >= 0 && tp < T;
+        const int64_t o = ((int64_t)nc * T + t) * D + dir;
+        const int64_t op = ((int64_t)nc * T + (has_prev ? tp : t)) * D + dir;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int u0 = uv[s] ? ub[s] : 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const f32x4 v = ctn_ld4(save + o * 5 * H + q * H + u0);
+                in.sv[q][s] = uv[s] ? v : zero4;
+            }
+            const f32x4 cpv = ctn_ld4(save + op * 5 * H + 4 * H + u0);
+            in.cp[s] = (uv[s] && has_prev) ? cpv : zero4;
+            const f32x4 d = ctn_ld4(dhout + o * H + u0);
+            in.dho[s] = uv[s] ? d : zero4;
+        }
+    };
+    StepIn cur;
+    load_step(dir == 0 ? T - 1 : 0, cur);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;                  // the reverse of the forward walk
+        StepIn nxt = cur;
+        if (step + 1 < T) load_step(dir == 0 ? t - 1 : t + 1, nxt);   // in flight during this step
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            f32x4 di, df, dg, dob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float iv = cur.sv[0][s][e], fv = cur.sv[1][s][e], gv = cur.sv[2][s][e], ov = cur.sv[3][s][e];
+                const float tc = tanhf_(cur.sv[4][s][e]);
+                const float dh = cur.dho[s][e] + dh_rec[s][e];
+                const float dc = dh * ov * (1.f - tc * tc) + dc_carry[s][e];
+                dob[e] = dh * tc * ov * (1.f - ov);
+                di[e] = dc * gv * iv * (1.f - iv);
+                dg[e] = dc * iv * (1.f - gv * gv);
+                df[e] = dc * cur.cp[s][e] * fv * (1.f - fv);
+                dc_carry[s][e] = dc * fv;
+                dgbuf[(0 * HP + ub[s] + e) * NSEQ + col] = di[e];
+                dgbuf[(1 * HP + ub[s] + e) * NSEQ + col] = df[e];
+                dgbuf[(2 * HP + ub[s] + e) * NSEQ + col] = dg[e];
+                dgbuf[(3 * HP + ub[s] + e) * NSEQ + col] = dob[e];
+            }
+            if (nv && uv[s]) {
+                float* o = dgates + (((int64_t)n * T + t) * D + dir) * 4 * H + ub[s];
+                ctn_st4(o, di);
+                ctn_st4(o + H, df);
+                ctn_st4(o + 2 * H, dg);
+                ctn_st4(o + 3 * H, dob);
+            }
+        }
+        __syncthreads();              // the step's gate gradients are complete in LDS
+        // dL/dh of the forward-order predecessor through the recurrence: W_hh^T . dgates; two partial sums per tile keep
+        // four independent MFMA chains in flight for NT = 2
+        f32x4 acc[NT][2];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) acc[s][0] = acc[s][1] = zero4;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const float b = dgbuf[(4 * kk + rg) * NSEQ + col];
+#pragma unroll
+            for (int s = 0; s < NT; ++s)
+                acc[s][kk & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[s][kk], b, acc[s][kk & 1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < NT; ++s) dh_rec[s] = acc[s][0] + acc[s][1];
+        cur = nxt;
+        __syncthreads();              // every wave is done reading dgbuf before the next step overwrites it
+    }
+}
+
+bool lstm_args_ok(int N, int T, int H, int D) { return N > 0 && T > 0 && H > 0 && H <= 128 && H % 4 == 0 && (D == 1 || D == 2); }
+
+}  // namespace
+
+extern "C" {
+
+int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int D, float* hout, float* save,
+                 void* stream) {
+    CTN_REQUIRE(xproj && whh && hout && save, "ctn_lstm_fwd: null pointer");
+    CTN_REQUIRE(lstm_args_ok(N, T, H, D), "ctn_lstm_fwd: needs hidden size <= 128 and a multiple of 4, 1 or 2 directions");
+    CTN_REQUIRE(ctn_aligned16(xproj) && ctn_aligned16(hout) && ctn_aligned16(save), "ctn_lstm_fwd: 16-byte alignment");
+    dim3 grid(ctn_cdiv(N, NSEQ), D);
+    if (H <= 64)
+        hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, dim3(NTH), 0, (hipStream_t)stream, xproj, whh, hout, save, N, T, H, D);
+    else
+        hipLaunchKernelGGL(lstm_fwd_kernel<2>, grid, dim3(NTH), 0, (hipStream_t)stream, xproj, whh, hout, save, N, T, H, D);
+    CTN_CHECK_LAUNCH("ctn_lstm_fwd");
+    return CTN_OK;
+}
+
+int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N, int T, int H, int D, float* dgates,
+                 void* stream) {
+    CTN_REQUIRE(dhout && save && whh && dgates, "ctn_lstm_bwd: null pointer");
+    CTN_REQUIRE(lstm_args_ok(N, T, H, D), "ctn_lstm_bwd: needs hidden size <= 128 and a multiple of 4, 1 or 2 directions");
+    CTN_REQUIRE(ctn_aligned16(dhout) && ctn_aligned16(dgates) && ctn_aligned16(save), "ctn_lstm_bwd: 16-byte alignment");
+    dim3 grid(ctn_cdiv(N, NSEQ), D);
+    if (H <= 64)
+        hipLaunchKernelGGL(lstm_bwd_kernel<1>, grid, dim3(NTH), 0, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+    else
+        hipLaunchKernelGGL(lstm_bwd_kernel<2>, grid, dim3(NTH), 0, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+    CTN_CHECK_LAUNCH("ctn_lstm_bwd");
+    return CTN_OK;
+}
+
+}  // extern "C"

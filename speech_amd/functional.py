@@ -274,6 +274,53 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dgamma.view(gamma.shape), dbeta.view(beta.shape), None, None
 
 
+# ------------------------------------------------------------------------------------------------ recurrence
+class LstmFn(torch.autograd.Function):
+    """nn.LSTM(batch_first=True, num_layers=1), one or two directions, zero initial state, on the persistent recurrence
+    kernels: x (N, T, F) -> (N, T, D*H).  The input projection of all steps is one GEMM in front of the recurrence
+    (torch.addmm, i.e. the GEMM library), the recurrence itself and its backward pass through time are ctn_lstm_fwd /
+    ctn_lstm_bwd, and the parameter / input gradients are GEMMs over all (sequence, step) pairs behind it.
+    params: weight_ih, weight_hh, bias_ih, bias_hh per direction, in nn.LSTM's _flat_weights order."""
+
+    @staticmethod
+    def forward(ctx, x, n_dir, *params):
+        ops._require_cuda(x)
+        N, T, F_in = x.shape
+        w_ih = [params[4 * d].detach() for d in range(n_dir)]
+        w_hh = [params[4 * d + 1].detach() for d in range(n_dir)]
+        bias = [(params[4 * d + 2] + params[4 * d + 3]).detach() for d in range(n_dir)]
+        H = w_hh[0].shape[1]
+        x2 = x.detach().reshape(N * T, F_in).float()
+        w_ih_all = torch.cat(w_ih, dim=0)                                  # (D*4H, F)
+        xproj = torch.addmm(torch.cat(bias), x2, w_ih_all.t()).view(N, T, n_dir, 4 * H)
+        whh = torch.stack(w_hh).contiguous()                              # (D, 4H, H)
+        hout, save = ops.lstm_fwd(xproj, whh)
+        ctx.saved = (x2, w_ih_all, whh, hout, save, n_dir, (N, T, F_in, H))
+        return hout.view(N, T, n_dir * H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, w_ih_all, whh, hout, save, n_dir, (N, T, F_in, H) = ctx.saved
+        dgates = ops.lstm_bwd(dout.contiguous().float().view(N, T, n_dir, H), save, whh)      # (N, T, D, 4H)
+        dg2 = dgates.view(N * T, n_dir * 4 * H)
+        dx = (dg2 @ w_ih_all).view(N, T, F_in) if ctx.needs_input_grad[0] else None
+        dw_ih_all = dg2.t() @ x2                                          # (D*4H, F)
+        db_all = dg2.sum(dim=0)
+        grads = []
+        for d in range(n_dir):
+            # h of the step before t in the direction's own order: shift by one step, zeros at its first step
+            hprev = torch.zeros((N, T, H), device=hout.device, dtype=torch.float32)
+            if T > 1:
+                if d == 0:
+                    hprev[:, 1:] = hout[:, :-1, d]
+                else:
+                    hprev[:, :-1] = hout[:, 1:, d]
+            dw_hh = dgates[:, :, d].reshape(N * T, 4 * H).t() @ hprev.view(N * T, H)
+            db = db_all[d * 4 * H:(d + 1) * 4 * H]
+            grads += [dw_ih_all[d * 4 * H:(d + 1) * 4 * H], dw_hh, db, db]
+        return (dx, None) + tuple(grads)
+
+
 # ------------------------------------------------------------------------------------------------ chunking
 class SegmentFn(torch.autograd.Function):
     """Segment1d.forward (src/models/transform.py:15-31) of the input zero-padded by (pad_left, as far as S chunks reach):

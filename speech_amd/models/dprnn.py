@@ -1,111 +1,120 @@
-"""Dual-path RNN blocks with the reference's interface and state_dict keys (src/models/dprnn.py:6-148).
+"""Dual-path RNN blocks (interface and state_dict keys of src/models/dprnn.py:6-148 of the reference).
 
-The layer norms run on this package's HIP kernels (on the (B, C, S*K) view the reference normalises); the recurrences
-are torch's nn.LSTM, i.e. MIOpen on the GPU, and the linear layers torch's nn.Linear (hipBLASLt): plain library
-calls, with no hand-written kernel here yet.  Permutations and the residual additions are torch tensor operations.
+A block applies the same three-stage unit twice, along two different axes of a (batch, features, chunks S, chunk size K)
+tensor: a recurrence along ONE of the two time axes with the other folded into the batch, a linear map back to the
+feature count, a layer norm over (features, S*K), and a residual connection.  `_PathRNN` is that unit; the intra-chunk
+block walks K (bidirectional always), the inter-chunk block walks S (one direction only when causal, and then with the
+cumulative norm).
+
+The recurrence runs on this package's persistent LSTM kernels (`LSTM` below: nn.LSTM's parameters, ctn_lstm_fwd/bwd
+through speech_amd.functional.LstmFn) -- one launch per sequence walk instead of two library launches per time step --
+with the input projection of all steps and the weight gradients as single large GEMMs.  The norms are this package's
+kernels as well; the linear layer is torch's (a plain library GEMM), the axis shuffles are tensor operations.
 """
 import torch.nn as nn
 
-from ..utils.model import choose_rnn
+from .. import ops
+from ..functional import LstmFn
 from ..utils.tasnet import choose_layer_norm
 
 EPS = 1e-12
 
 
-class DPRNN(nn.Module):
-    """src/models/dprnn.py:8-28"""
+class LSTM(nn.LSTM):
+    """nn.LSTM as a parameter container -- same names, shapes and initialisation, so checkpoints interchange with the
+    reference's -- with the forward pass on the persistent recurrence kernels.  What those kernels do not cover (an
+    initial state, several layers, projections, hidden sizes above 128 or not a multiple of 4, time-major input) takes
+    nn.LSTM's own forward, i.e. the GPU library's LSTM."""
 
-    def __init__(self, num_features, hidden_channels, num_blocks=6, norm=True, causal=False, rnn_type='lstm', eps=EPS):
+    def _persistent_ok(self, input, hx):
+        return (hx is None and input.is_cuda and input.dim() == 3 and self.batch_first and self.num_layers == 1
+                and self.bias and not self.proj_size and self.hidden_size <= ops.LSTM_MAX_HIDDEN
+                and self.hidden_size % 4 == 0 and (not self.training or self.dropout == 0.0))
+
+    def forward(self, input, hx=None):
+        if not self._persistent_ok(input, hx):
+            return super().forward(input, hx)
+        output = LstmFn.apply(input, 2 if self.bidirectional else 1, *self._flat_weights)
+        return output, None                          # the final (h, c) pair is not formed: the dual-path blocks drop it
+
+    def flatten_parameters(self):
+        """The library LSTM wants its weights in one buffer; the persistent kernels read them where they are."""
+        if not all(w.is_cuda for w in self._flat_weights) or self.hidden_size > ops.LSTM_MAX_HIDDEN or self.hidden_size % 4:
+            super().flatten_parameters()
+
+
+class _PathRNN(nn.Module):
+    """Recurrence along one axis of (batch, features, S, K), linear map, norm, residual.
+
+    walk_chunks=False: sequences are the chunks' interiors (length K, batch * S of them): src/models/dprnn.py:76-94.
+    walk_chunks=True: sequences run across chunks (length S, batch * K of them): src/models/dprnn.py:128-148; the norm
+    then sees the frames in (K, S) order, as the reference lays them out before normalising."""
+
+    def __init__(self, num_features, hidden_channels, walk_chunks, bidirectional, norm, norm_name, causal, rnn_type, eps):
         super().__init__()
-        net = []
-        for _ in range(num_blocks):
-            net.append(DPRNNBlock(num_features, hidden_channels, norm=norm, causal=causal, rnn_type=rnn_type, eps=eps))
-        self.net = nn.Sequential(*net)
+        if rnn_type != 'lstm':
+            raise NotImplementedError("Not support {}.".format(rnn_type))
+        self.num_features, self.hidden_channels = num_features, hidden_channels
+        self.walk_chunks = walk_chunks
+        self.norm = norm
+        self.rnn = LSTM(input_size=num_features, hidden_size=hidden_channels, batch_first=True, bidirectional=bidirectional)
+        self.fc = nn.Linear((2 if bidirectional else 1) * hidden_channels, num_features)
+        if norm:
+            self.norm1d = choose_layer_norm(norm_name, num_features, causal=causal, eps=eps)
 
     def forward(self, input):
-        """(batch_size, num_features, S, chunk_size) -> the same shape"""
-        return self.net(input)
+        batch_size, num_features, S, K = input.size()
+        # (batch, features, S, K) -> (sequences, steps, features)
+        order = (0, 3, 2, 1) if self.walk_chunks else (0, 2, 3, 1)
+        outer, steps = (K, S) if self.walk_chunks else (S, K)
+        sequences = input.permute(*order).reshape(batch_size * outer, steps, num_features)
+        y, _ = self.rnn(sequences)
+        y = self.fc(y)                                                     # (sequences, steps, features)
+        y = y.view(batch_size, outer * steps, num_features).permute(0, 2, 1).contiguous()
+        if self.norm:
+            y = self.norm1d(y)                                             # over (features, outer * steps)
+        y = y.reshape(batch_size, num_features, outer, steps)
+        if self.walk_chunks:
+            y = y.permute(0, 1, 3, 2)                                      # back to (batch, features, S, K)
+        return y + input
+
+
+class IntraChunkRNN(_PathRNN):
+    """src/models/dprnn.py:50-95"""
+
+    def __init__(self, num_features, hidden_channels, norm=True, rnn_type='lstm', eps=EPS):
+        super().__init__(num_features, hidden_channels, walk_chunks=False, bidirectional=True, norm=norm, norm_name='gLN',
+                         causal=False, rnn_type=rnn_type, eps=eps)
+
+
+class InterChunkRNN(_PathRNN):
+    """src/models/dprnn.py:97-148"""
+
+    def __init__(self, num_features, hidden_channels, causal, norm=True, rnn_type='lstm', eps=EPS):
+        super().__init__(num_features, hidden_channels, walk_chunks=True, bidirectional=not causal, norm=norm,
+                         norm_name='cLN' if causal else 'gLN', causal=causal, rnn_type=rnn_type, eps=eps)
 
 
 class DPRNNBlock(nn.Module):
-    """src/models/dprnn.py:30-48"""
+    """src/models/dprnn.py:30-48: the intra-chunk unit, then the inter-chunk unit."""
 
     def __init__(self, num_features, hidden_channels, causal, norm=True, rnn_type='lstm', eps=EPS):
         super().__init__()
         self.intra_chunk_block = IntraChunkRNN(num_features, hidden_channels, norm=norm, rnn_type=rnn_type, eps=eps)
-        self.inter_chunk_block = InterChunkRNN(num_features, hidden_channels, norm=norm, causal=causal, rnn_type=rnn_type,
+        self.inter_chunk_block = InterChunkRNN(num_features, hidden_channels, causal=causal, norm=norm, rnn_type=rnn_type,
                                                eps=eps)
 
     def forward(self, input):
         return self.inter_chunk_block(self.intra_chunk_block(input))
 
 
-class IntraChunkRNN(nn.Module):
-    """src/models/dprnn.py:50-95: bidirectional recurrence along each chunk, linear back to num_features, gLN over
-    (C, S*K), residual."""
+class DPRNN(nn.Module):
+    """src/models/dprnn.py:8-28: num_blocks dual-path blocks in sequence, (batch, features, S, K) in and out."""
 
-    def __init__(self, num_features, hidden_channels, norm=True, rnn_type='lstm', eps=EPS):
+    def __init__(self, num_features, hidden_channels, num_blocks=6, norm=True, causal=False, rnn_type='lstm', eps=EPS):
         super().__init__()
-        self.num_features, self.hidden_channels = num_features, hidden_channels
-        num_directions = 2
-        self.norm = norm
-        if rnn_type == 'lstm':
-            self.rnn = choose_rnn(rnn_type, input_size=num_features, hidden_size=hidden_channels, batch_first=True,
-                                  bidirectional=True)
-        else:
-            raise NotImplementedError("Not support {}.".format(rnn_type))
-        self.fc = nn.Linear(num_directions * hidden_channels, num_features)
-        if self.norm:
-            self.norm1d = choose_layer_norm('gLN', num_features, causal=False, eps=eps)
+        self.net = nn.Sequential(*[DPRNNBlock(num_features, hidden_channels, causal=causal, norm=norm, rnn_type=rnn_type,
+                                              eps=eps) for _ in range(num_blocks)])
 
     def forward(self, input):
-        num_features = self.num_features
-        batch_size, _, S, chunk_size = input.size()
-        self.rnn.flatten_parameters()
-        residual = input
-        x = input.permute(0, 2, 3, 1).contiguous()                 # (batch_size, S, chunk_size, num_features)
-        x = x.view(batch_size * S, chunk_size, num_features)
-        x, _ = self.rnn(x)                                         # (batch_size*S, chunk_size, 2*hidden_channels)
-        x = self.fc(x)
-        x = x.view(batch_size, S * chunk_size, num_features)
-        x = x.permute(0, 2, 1).contiguous()                        # (batch_size, num_features, S*chunk_size)
-        if self.norm:
-            x = self.norm1d(x)
-        x = x.reshape(batch_size, num_features, S, chunk_size)
-        return x + residual
-
-
-class InterChunkRNN(nn.Module):
-    """src/models/dprnn.py:97-148: recurrence across chunks (one direction if causal), linear, gLN / cLN over
-    (C, K*S) in chunk-major order as the reference lays it out, residual."""
-
-    def __init__(self, num_features, hidden_channels, causal, norm=True, rnn_type='lstm', eps=EPS):
-        super().__init__()
-        self.num_features, self.hidden_channels = num_features, hidden_channels
-        self.norm = norm
-        if rnn_type != 'lstm':
-            raise NotImplementedError("Not support {}.".format(rnn_type))
-        num_directions = 1 if causal else 2
-        self.rnn = choose_rnn(rnn_type, input_size=num_features, hidden_size=hidden_channels, batch_first=True,
-                              bidirectional=not causal)
-        self.fc = nn.Linear(num_directions * hidden_channels, num_features)
-        if self.norm:
-            norm_name = 'cLN' if causal else 'gLN'
-            self.norm1d = choose_layer_norm(norm_name, num_features, causal=causal, eps=eps)
-
-    def forward(self, input):
-        num_features = self.num_features
-        batch_size, _, S, chunk_size = input.size()
-        self.rnn.flatten_parameters()
-        residual = input
-        x = input.permute(0, 3, 2, 1).contiguous()                 # (batch_size, chunk_size, S, num_features)
-        x = x.view(batch_size * chunk_size, S, num_features)
-        x, _ = self.rnn(x)
-        x = self.fc(x)
-        x = x.view(batch_size, chunk_size * S, num_features)
-        x = x.permute(0, 2, 1).contiguous()                        # (batch_size, num_features, chunk_size*S)
-        if self.norm:
-            x = self.norm1d(x)
-        x = x.reshape(batch_size, num_features, chunk_size, S)
-        x = x.permute(0, 1, 3, 2).contiguous()
-        return x + residual
+        return self.net(input)

@@ -217,6 +217,34 @@ def overlap_add(y, P, T, pad_left=0):
     return x
 
 
+# ------------------------------------------------------------------------------------------------ recurrence
+LSTM_MAX_HIDDEN = 128
+
+
+def lstm_fwd(xproj, whh):
+    """xproj (N, T, D, 4H) dense fp32, whh (D, 4H, H) -> hout (N, T, D, H), save (N, T, D, 5, H); see ctn_lstm_fwd."""
+    lib = _lib.load()
+    _require_cuda(xproj, whh)
+    N, T, D, G = xproj.shape
+    H = G // 4
+    assert xproj.is_contiguous() and whh.is_contiguous() and tuple(whh.shape) == (D, 4 * H, H)
+    hout = torch.empty((N, T, D, H), device=xproj.device, dtype=torch.float32)
+    save = torch.empty((N, T, D, 5, H), device=xproj.device, dtype=torch.float32)
+    _lib.check(lib.ctn_lstm_fwd(_ptr(xproj), _ptr(whh), N, T, H, D, _ptr(hout), _ptr(save), _stream()), "ctn_lstm_fwd")
+    return hout, save
+
+
+def lstm_bwd(dhout, save, whh):
+    """dhout (N, T, D, H) -> dgates (N, T, D, 4H) = gradient w.r.t. xproj; see ctn_lstm_bwd."""
+    lib = _lib.load()
+    _require_cuda(dhout, save, whh)
+    N, T, D, H = dhout.shape
+    assert dhout.is_contiguous() and save.is_contiguous() and tuple(save.shape) == (N, T, D, 5, H)
+    dgates = torch.empty((N, T, D, 4 * H), device=dhout.device, dtype=torch.float32)
+    _lib.check(lib.ctn_lstm_bwd(_ptr(dhout), _ptr(save), _ptr(whh), N, T, H, D, _ptr(dgates), _stream()), "ctn_lstm_bwd")
+    return dgates
+
+
 # ------------------------------------------------------------------------------------------------ norms
 def transpose(src2d, dst, ldd, coff=0):
     lib = _lib.load()

@@ -2,7 +2,8 @@
 modules (tests/golden/dprnn.npz from tools/gen_golden_dprnn.py): Segment1d / OverlapAdd1d with the separator's
 paddings, forward and backward, bit-exact; whole networks (small bidirectional, small causal 3-speaker, the recipe's
 default configuration on a 4 s 16 kHz mixture) -- waveforms and loss at 1e-4, permutations bit-exact, gradients at 1e-3
-of each tensor's largest entry (the recurrences run in MIOpen against PyTorch's CPU LSTM in the fixture)."""
+of each tensor's largest entry (the recurrences run on the persistent LSTM kernels, tests/test_lstm_gpu.py, against PyTorch's
+CPU LSTM in the fixture)."""
 import numpy as np
 import pytest
 import torch

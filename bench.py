@@ -432,7 +432,7 @@ def main():
         for name in ("dw_fwd", "dw_bwd"):
             d = prof[name]
             gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
-            row = dict(bound="hbm", kernel=name + "_kernel", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
+            row = dict(bound="hbm", kernel={"dw_fwd": "dw_fwd_row_kernel", "dw_bwd": "dw_bwd_gln_rc_kernel"}[name], achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
                        unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
                        traffic=profiled_traffic(name, args.batch),
                        launches_per_step=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 1),

@@ -102,6 +102,32 @@ int ctn_probe_mfma_f32(const float* in, float* out, int blocks, int iters, void*
  * (M_out, K_in) out k-major for ctn_gemm_nn. */
 int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64_t coff, void* stream);
 
+/* Prepared weights.  In CTN_ARITH_BF16X3 the A operand of ctn_gemm_nn (a weight matrix, read by every block of the
+ * launch) can be split into its three bf16 pieces ONCE per optimizer step instead of by every wave that reads it, and
+ * laid out the way the matrix instruction takes it.  A prepared K x M matrix (A[k][m], k the contraction index) is
+ *   bf16 planes[3][Kp / 8][Mp][8],  Kp = K rounded up to 16, Mp = M rounded up to 128  (ctn_weight_prep_bytes(K, M)),
+ * planes[p][g][m][q] = piece p (0 = leading eight bits, 1, 2 = the following eight each) of A[8 g + q][m], zero beyond
+ * K and M: the caller zero-fills the buffer once, ctn_weight_prep writes only what its items cover.
+ * An item copies one fp32 source matrix (rows x cols, row pitch ld) into the prepared matrix `dst` (logical size K x M)
+ * at (k_off, m_off): transpose = 0 takes source rows as k (A[k_off + r][m_off + c] = src[r][c]; a Conv1d weight
+ * (out, in) used for the input gradient), transpose = 1 takes source rows as m (A[k_off + c][m_off + r] = src[r][c];
+ * the same weight used in the forward pass).  Several items may fill one prepared matrix (the two heads of a residual
+ * layer side by side).  k_off % 8 == 0; dst 16-byte aligned.  `items` is host memory, read during the call; any number
+ * of items, a launch per 56 of them.  Replaces ctn_transpose for callers in that arithmetic mode; no counterpart in the
+ * reference (nn.Conv1d reads its weight where it is). */
+typedef struct {
+    const float* src; int64_t ld;
+    void* dst;
+    int32_t rows, cols;
+    int32_t transpose;
+    int32_t k_off, m_off;
+    int32_t K, M;                     /* logical size of the prepared matrix dst belongs to */
+    int32_t pad0;
+} ctn_wprep_item;
+int64_t ctn_weight_prep_bytes(int K, int M);
+int ctn_weight_prep(const ctn_wprep_item* items, int n_items, void* stream);
+int ctn_sizeof_wprep_item(void);
+
 /* Chunking for dual-path separators and its adjoint.
  * ctn_segment: y[b][c][s][k] = xpad[b][c][s*P + k] with y dense (batch, C, S, K) and xpad = x (rows of T frames, pitch
  * ldx, batch stride xbs) zero-padded by pad_left frames in front and as far as the S chunks reach behind.  Replaces
@@ -132,6 +158,25 @@ int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int 
                  void* stream);
 int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N, int T, int H, int D, float* dgates,
                  void* stream);
+
+/* Finishing a global layer norm's reduction inside the launch that produces its sums (field `fin` of the argument structs
+ * below; it applies to that launch's `esums` / `isums`).  With `count` given, the block that adds the LAST partial sums
+ * of a batch element also turns the element's sums into the two scalars the consumers read, so no launch of
+ * ctn_gln_finalize / ctn_gln_bwd_coefs is needed behind the producer:
+ *   CTN_FIN_STATS: out0 = mean = S1/n, out1 = rstd = 1/sqrt(S2/n - mean^2 + eps)          (what ctn_gln_finalize writes)
+ *   CTN_FIN_COEFS: out0 = c1 = -rstd*S1/n, out1 = c2 = -rstd^2*S2/n, rstd read from `rstd` (what ctn_gln_bwd_coefs writes)
+ * count: uint32[batch], ZERO before the launch (every block of a batch element increments its entry once, after its
+ * additions have been performed); count NULL = off.  Per-sample (gLN) sums only.  No counterpart in the reference. */
+#define CTN_FIN_STATS 0
+#define CTN_FIN_COEFS 1
+typedef struct {
+    uint32_t* count;
+    float* out0; float* out1;
+    const float* rstd;
+    double n;
+    float eps;
+    int32_t kind;
+} ctn_finish;
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise (1x1) convolution as a batched GEMM on f32 MFMA:  Y[b] = A^T-layout(W) . xform(X[b])
@@ -172,6 +217,11 @@ typedef struct {
     const float* E; int64_t lde, ebs; /* epilogue input (batch, M, lde) */
     const float* emean; const float* erstd; int64_t essb, esst;
     const float* egamma;              /* [M] */
+    /* A in prepared form (ctn_weight_prep below), or NULL.  When given, A / lda / A2 / lda2 are not read and the call
+     * must satisfy: arith CTN_ARITH_DEFAULT or CTN_ARITH_BF16X3, M > 64, M % 4 == 0, K % 16 == 0, K1 % 16 == 0, K <= 4096
+     * and the 16-byte alignments of the LDS-DMA kernel (it is refused otherwise, there is no slower path behind it). */
+    const void* A_prep;
+    ctn_finish fin;                   /* STATS / NORMBWD epilogue with esums: finish the reduction in this launch */
 } ctn_gemm_nn_args;
 
 int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream);
@@ -269,6 +319,7 @@ typedef struct {
     const float* alpha_out;           /* statistics of prelu(y, alpha_out); NULL: no statistics */
     double* esums;                    /* [batch][CTN_STAT_SLOTS][2] += */
     float* ecol; int64_t ecol_ld;     /* [batch][2][ecol_ld] += */
+    ctn_finish fin;                   /* esums: finish the reduction in this launch (CTN_FIN_STATS) */
 } ctn_dw_fwd_args;
 
 int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream);
@@ -309,6 +360,7 @@ typedef struct {
      * (oflags NORMBWD, xflags PRELU|NORM, per-sample statistics, T <= 4096, P <= 4); any other launch needs y2. */
     const float* bias;
     int32_t recompute_y2; int32_t pad1;
+    ctn_finish fin;                   /* isums: finish the reduction in this launch (CTN_FIN_COEFS) */
 } ctn_dw_bwd_args;
 
 int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream);

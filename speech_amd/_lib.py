@@ -26,6 +26,13 @@ _f32 = C.c_float
 _f64 = C.c_double
 
 
+class Finish(C.Structure):
+    _fields_ = [("count", _p), ("out0", _p), ("out1", _p), ("rstd", _p), ("n", _f64), ("eps", _f32), ("kind", _i32)]
+
+
+FIN_STATS, FIN_COEFS = 0, 1
+
+
 class GemmNNArgs(C.Structure):
     _fields_ = [
         ("M", _i32), ("T", _i32), ("K", _i32), ("batch", _i32),
@@ -49,6 +56,16 @@ class GemmNNArgs(C.Structure):
         ("E", _p), ("lde", _i64), ("ebs", _i64),
         ("emean", _p), ("erstd", _p), ("essb", _i64), ("esst", _i64),
         ("egamma", _p),
+        ("A_prep", _p),
+        ("fin", Finish),
+    ]
+
+
+class WPrepItem(C.Structure):
+    _fields_ = [
+        ("src", _p), ("ld", _i64), ("dst", _p),
+        ("rows", _i32), ("cols", _i32), ("transpose", _i32), ("k_off", _i32), ("m_off", _i32),
+        ("K", _i32), ("M", _i32), ("pad0", _i32),
     ]
 
 
@@ -85,6 +102,7 @@ class DwFwdArgs(C.Structure):
         ("y", _p), ("ldy", _i64), ("ybs", _i64),
         ("alpha_out", _p), ("esums", _p),
         ("ecol", _p), ("ecol_ld", _i64),
+        ("fin", Finish),
     ]
 
 
@@ -108,6 +126,7 @@ class DwBwdArgs(C.Structure):
         ("isums", _p), ("icol", _p), ("icol_ld", _i64),
         ("dgamma1", _p), ("dbeta1", _p),
         ("bias", _p), ("recompute_y2", _i32), ("pad1", _i32),
+        ("fin", Finish),
     ]
 
 
@@ -122,6 +141,9 @@ PROTOTYPES = {
     "ctn_probe_copy": (C.c_int, [_p, _p, _p, _i64, _p]),
     "ctn_probe_mfma_f32": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "ctn_transpose": (C.c_int, [_p, C.c_int, C.c_int, _p, _i64, _i64, _p]),
+    "ctn_sizeof_wprep_item": (C.c_int, []),
+    "ctn_weight_prep_bytes": (_i64, [C.c_int, C.c_int]),
+    "ctn_weight_prep": (C.c_int, [C.POINTER(WPrepItem), C.c_int, _p]),
     "ctn_segment": (C.c_int, [_p, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "ctn_overlap_add": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _i64, _i64, _p]),
     "ctn_lstm_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
@@ -170,6 +192,7 @@ _STRUCT_SIZES = {
     "ctn_sizeof_gemm_nt_args": GemmNTArgs,
     "ctn_sizeof_dw_fwd_args": DwFwdArgs,
     "ctn_sizeof_dw_bwd_args": DwBwdArgs,
+    "ctn_sizeof_wprep_item": WPrepItem,
 }
 
 _lib = None

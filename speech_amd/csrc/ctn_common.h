@@ -91,6 +91,46 @@ __device__ __forceinline__ double ctn_block_sum_f64(double v, double* smem) {
     return tot;
 }
 
+// Finishing a gLN reduction in the producing launch (ctn_finish in include/ctn.h).  EVERY thread of EVERY block that
+// belongs to batch element b calls this once, after the block's additions to sums_b (the element's
+// [CTN_STAT_SLOTS][2] doubles) have been issued; `nblocks` is the number of such blocks.  All values travel through
+// device-scope atomics -- additions, the ticket, the final loads -- so "my additions have been performed" (vmcnt(0))
+// before "I take my ticket" is all the ordering the hand-over needs: no cache has to be written back or invalidated.
+__device__ __forceinline__ void ctn_finish_sums(const ctn_finish& f, const double* sums_b, int b, unsigned nblocks,
+                                                unsigned* flag /* one word of LDS */) {
+    if (f.count == nullptr) return;                        // uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(f.count + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = ticket == nblocks - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u || threadIdx.x != 0) return;
+    double S1 = 0.0, S2 = 0.0;                             // slot order and arithmetic of the stand-alone kernels
+    for (int s = 0; s < CTN_STAT_SLOTS; ++s) {
+        S1 += __hip_atomic_load(sums_b + 2 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S2 += __hip_atomic_load(sums_b + 2 * s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (f.kind == CTN_FIN_STATS) {
+        const double m = S1 / f.n;
+        double var = S2 / f.n - m * m;
+        if (var < 0.0) var = 0.0;
+        f.out0[b] = (float)m;
+        f.out1[b] = (float)(1.0 / sqrt(var + (double)f.eps));
+    } else {
+        const double r = f.rstd[b];
+        f.out0[b] = (float)(-r * S1 / f.n);
+        f.out1[b] = (float)(-r * r * S2 / f.n);
+    }
+}
+
+// Host-side check of a ctn_finish request.
+static inline bool ctn_finish_ok(const ctn_finish& f) {
+    if (f.count == nullptr) return true;
+    return f.out0 && f.out1 && f.n > 0 && (f.kind == CTN_FIN_STATS || (f.kind == CTN_FIN_COEFS && f.rstd));
+}
+
 __device__ __forceinline__ f32x4 ctn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void ctn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // streaming variants (touched once by this kernel): non-temporal hint, the lines do not displace reusable data in L2

@@ -180,6 +180,8 @@ __global__ __launch_bounds__(NTH) void dw_fwd_kernel(const ctn_dw_fwd_args a, co
         float v[2] = {s1, s2};
         const float tot = ctn_block_sum<2>(v, red);
         if (tid < 2) atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
+        __shared__ unsigned fin_flag;
+        ctn_finish_sums(a.fin, a.esums + (int64_t)b * CTN_STAT_SLOTS * 2, b, gridDim.x * gridDim.y, &fin_flag);
     }
 }
 
@@ -263,6 +265,8 @@ __global__ __launch_bounds__(NTH) void dw_fwd_row_kernel(const ctn_dw_fwd_args a
     float sv[2] = {s1, s2};
     const float tot = ctn_block_sum<2>(sv, red);
     if (tid < 2) atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
+    __shared__ unsigned fin_flag;
+    ctn_finish_sums(a.fin, a.esums + (int64_t)b * CTN_STAT_SLOTS * 2, b, gridDim.x, &fin_flag);
 }
 
 // Per-frame sums of a block's time tile -> global rows col[0][t], col[1][t].  A thread holds four consecutive frames;
@@ -569,6 +573,9 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
         const float tot = ctn_block_sum<3>(v, red);
         if (tid == 0 && obwd && a.dalpha2) atomicAdd(a.dalpha2 + ctn_slot(), (double)tot);
         if (!a.cln && a.isums && (tid == 1 || tid == 2)) atomicAdd(a.isums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + (tid - 1), (double)tot);
+        __shared__ unsigned fin_flag;
+        if (!a.cln && a.isums)
+            ctn_finish_sums(a.fin, a.isums + (int64_t)b * CTN_STAT_SLOTS * 2, b, gridDim.x * gridDim.y, &fin_flag);
     }
     if (a.cln && a.icol) {
         const int t = t0 + 4 * tid;
@@ -895,6 +902,8 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_kernel(const ctn_dw_bwd_args a
     if ((tid == 6 || tid == 7) && a.isums)
         atomicAdd(a.isums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + (tid - 6), (double)tot);
     if (tid >= 8 && tid < 8 + P) atomicAdd(a.dw + (int64_t)c * P + (tid - 8), tot);
+    __shared__ unsigned fin_flag;
+    if (a.isums) ctn_finish_sums(a.fin, a.isums + (int64_t)b * CTN_STAT_SLOTS * 2, b, gridDim.x, &fin_flag);
 }
 
 // ------------------------------------------------------------------------------------------ backward, gLN rows, y2 recomputed
@@ -1058,6 +1067,8 @@ __global__ __launch_bounds__(NTH) void dw_bwd_gln_rc_kernel(const ctn_dw_bwd_arg
     if ((tid == 6 || tid == 7) && a.isums)
         atomicAdd(a.isums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + (tid - 6), (double)tot);
     if (tid >= 10 && tid < 10 + P) atomicAdd(a.dw + (int64_t)c * P + (tid - 10), tot);
+    __shared__ unsigned fin_flag;
+    if (a.isums) ctn_finish_sums(a.fin, a.isums + (int64_t)b * CTN_STAT_SLOTS * 2, b, gridDim.x, &fin_flag);
 }
 
 bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
@@ -1090,6 +1101,7 @@ int ctn_dw_fwd(const ctn_dw_fwd_args* args, void* stream) {
         CTN_REQUIRE(a.mean && a.rstd && a.gamma && a.beta, "ctn_dw_fwd: NORM needs mean, rstd, gamma, beta");
     const bool stats = a.alpha_out || a.esums || a.ecol;
     if (stats) CTN_REQUIRE(a.cln ? (a.ecol && a.ecol_ld >= a.T) : (a.esums != nullptr), "ctn_dw_fwd: statistics buffer");
+    CTN_REQUIRE(ctn_finish_ok(a.fin) && (!a.fin.count || (a.esums && !a.cln)), "ctn_dw_fwd: fin needs esums (gLN), out0, out1, n");
     int CG, TT, lw;
     pick_tile(a.T, (a.P - 1) * a.dilation, a.cln != 0, 1, &CG, &TT, &lw);
     CTN_REQUIRE((size_t)lw * 4 <= 64 * 1024, "ctn_dw_fwd: dilation halo too large for LDS");
@@ -1148,6 +1160,7 @@ int ctn_dw_bwd(const ctn_dw_bwd_args* args, void* stream) {
     if (a.xflags & CTN_XF_NORM)
         CTN_REQUIRE(a.mean1 && a.rstd1 && a.gamma1 && a.beta1, "ctn_dw_bwd: input-side NORM needs stats, gamma1, beta1");
     if (a.cln) CTN_REQUIRE(!a.icol || a.icol_ld >= a.T, "ctn_dw_bwd: icol_ld < T");
+    CTN_REQUIRE(ctn_finish_ok(a.fin) && (!a.fin.count || (a.isums && !a.cln)), "ctn_dw_bwd: fin needs isums (gLN), out0, out1, n, rstd");
     const int padR = (a.P - 1) * a.dilation - a.pad_left;
     const int H = a.pad_left > padR ? a.pad_left : padR;
     hipStream_t s = (hipStream_t)stream;

@@ -380,6 +380,9 @@ __global__ __launch_bounds__(NTH) void gemm_nn_kernel(const ctn_gemm_nn_args a, 
             atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
         }
     }
+    __shared__ unsigned fin_flag;
+    if ((emode == CTN_EPI_STATS || emode == CTN_EPI_NORMBWD) && a.esums != nullptr)
+        ctn_finish_sums(a.fin, a.esums + (int64_t)b * CTN_STAT_SLOTS * 2, b, tiles_m * tiles_n, &fin_flag);
 }
 
 // ================================================================================================
@@ -450,9 +453,29 @@ __device__ __forceinline__ void ctn_split_bf16_3(const float (&x)[8], bf16x8& hi
     hi = h.v, mid = m.v, lo = l.v;
 }
 
+// LDS stores the compiler does not see as such.  It orders every LDS store it knows of behind ALL outstanding
+// global-to-LDS DMA (s_waitcnt vmcnt(0)), whatever their addresses, which would end the prefetch the DMA exists for.
+// The caller orders these stores itself: s_waitcnt lgkmcnt(0) before the barrier that publishes them.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ctn_lds_store16_untracked(void* p, u32x4 v) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ctn_lds_store8_untracked(void* p, u32x2 v) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
 // SPLIT = 2: the products run on the bf16 MFMA (16 k per instruction, 8 passes) from operands split into two bf16
 // pieces, three instructions per tile and k-tile -- hi*hi + hi*lo + lo*hi, fp32 accumulation -- instead of eight f32
 // MFMAs of 16 passes each.  SPLIT = 3: three pieces and the six leading products, which keeps all 24 mantissa bits.
+// SPLIT = 4: the arithmetic of SPLIT = 3 with each operand element split ONCE per block instead of once per wave that
+// reads it.  A arrives prepared (ctn_weight_prep: three bf16 planes in fragment order, fetched by DMA as they are); the
+// fp32 X tile lands in a ring of three buffers and is transformed, split and written to LDS as fragments by all threads
+// -- one (column, k-group) each -- one k-tile ahead of the MFMAs that consume it.  The MFMA phase then is six 16-byte
+// LDS reads per fragment set and the matrix instructions; products and their order are those of SPLIT = 3, so the
+// results are bit-identical.
 template <int FBN_, int XF, bool BWD, int SPLIT = 0>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : 2), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
@@ -492,7 +515,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     const float alpha = a.alpha ? a.alpha[0] : 1.f;
     const int nk = (K + FBK - 1) / FBK;
     const int Kp = nk * FBK;
-    float* Gs = lds + 2 * BUF;
+    constexpr bool PREP = SPLIT == 4;
+    constexpr int APSZ = 3 * 2 * FBM * 4;                 // PREP: floats of one buffer of A fragments (3 planes x 16 k)
+    constexpr int BPSZ = 3 * 2 * FBN_ * 4;                //       ... of X fragments
+    constexpr int XLSZ = TILE_X * (BWD ? 2 : 1);          //       ... of one landing buffer (X and, NORMBWD, X2)
+    float* Gs = lds + (PREP ? 2 * APSZ + 2 * BPSZ + 3 * XLSZ : 2 * BUF);
     float* Bes = Gs + Kp;
     constexpr bool has_norm = BWD || (XF & CTN_XF_NORM) != 0;
     if (has_norm) {
@@ -612,6 +639,155 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (PREP) {
+        float* const APb = lds;
+        float* const BPb = lds + 2 * APSZ;
+        float* const XLb = BPb + 2 * BPSZ;
+        const int KG = 2 * nk, Mp = tiles_m * FBM;        // k-groups and padded row count of the prepared matrix
+        const auto rAp = __builtin_amdgcn_make_buffer_rsrc((void*)a.A_prep, 0, 3 * KG * Mp * 16, 0x00020000);
+        const int voAp = lane * 16;
+#define CTN_BLDS16(rs, lp, vo, so) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+        // A fragments of k-tile kt: 12 pieces of 1 KiB (plane, k-group, half of the 128 rows), three per wave
+        auto issue_ap = [&](int kt, float* ap) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                const int q = wv * 3 + pp;
+                const int pl = q >> 2, h = (q >> 1) & 1, mh = q & 1;
+                CTN_BLDS16(rAp, ap + q * 256, voAp, ((pl * KG + 2 * kt + h) * Mp + m_blk + mh * 64) * 16);
+            }
+        };
+        auto issue_x = [&](int kt, float* xl) {
+            const int k0 = kt * FBK;
+#pragma unroll
+            for (int pp = 0; pp < XPW; ++pp) {
+                const int p = wv * XPW + pp;
+                if (k0 < K1)
+                    CTN_BLDS16(rX1, xl + p * 256, voX1, (k0 + XRP * p) * ldX1 * 4);
+                else
+                    CTN_BLDS16(rXb, xl + p * 256, voXb, (k0 - K1 + XRP * p) * ldXb * 4);
+                if (BWD) CTN_BLDS16(rX2, xl + TILE_X + p * 256, voX2, (k0 + XRP * p) * ldX2 * 4);
+            }
+        };
+#undef CTN_BLDS16
+        constexpr int NXOPS = XPW * (BWD ? 2 : 1);        // DMA instructions per wave and landing buffer
+        auto wait_but_newest_x = [&](bool newest_in_flight) {   // in-order completion: all but the last NXOPS loads
+            // lgkmcnt(0): the fragment stores of convert() are invisible to the compiler's own counting
+            if (newest_in_flight) {
+                if constexpr (NXOPS == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                else if constexpr (NXOPS == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+        };
+        static_assert(NXOPS == 1 || NXOPS == 2 || NXOPS == 4, "landing-buffer DMA count");
+        // conversion: thread -> column ccol of the tile and KPT consecutive k rows starting at ckb
+        constexpr int KPT = FBN_ / 16;
+        const int ccol = tid % FBN_, ckb = (tid / FBN_) * KPT;
+        float cmean = 0.f, crstd = 1.f, cc1 = 0.f, cc2 = 0.f;
+        if (has_norm) {
+            const int t = min(t_blk + ccol, T - 1);
+            const int64_t si = (int64_t)b * a.ssb + (int64_t)t * a.sst;
+            cmean = a.mean[si];
+            crstd = a.rstd[si];
+            if (BWD) {
+                cc1 = a.c1[si];
+                cc2 = a.c2[si];
+            }
+        }
+        const float cnmr = -cmean * crstd, cc1m = cc1 - cmean * cc2;
+        auto convert = [&](const float* xl, float* bp, int k0) {
+            float f[KPT];
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const int k = ckb + q;
+                float v = xl[k * FBN_ + ccol];
+                if (BWD) {
+                    const float y = xl[TILE_X + k * FBN_ + ccol];
+                    const float sl = y > 0.f ? 1.f : alpha;
+                    v = sl * __builtin_fmaf(Gs[k0 + k] * v, crstd, __builtin_fmaf(sl * y, cc2, cc1m));
+                }
+                if (XF & CTN_XF_PRELU) v = ctn_prelu_med(v, alpha, plim);
+                if (XF & CTN_XF_NORM) v = __builtin_fmaf(__builtin_fmaf(v, crstd, cnmr), Gs[k0 + k], Bes[k0 + k]);
+                f[q] = v;
+            }
+            unsigned ph[KPT / 2], pm[KPT / 2], pl[KPT / 2];
+#pragma unroll
+            for (int i = 0; i < KPT / 2; ++i) {           // the truncating three-piece split of ctn_split_bf16_3
+                const unsigned x0 = __float_as_uint(f[2 * i]), x1 = __float_as_uint(f[2 * i + 1]);
+                ph[i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                const float r0 = f[2 * i] - __uint_as_float(x0 & 0xffff0000u), r1 = f[2 * i + 1] - __uint_as_float(x1 & 0xffff0000u);
+                const unsigned ru0 = __float_as_uint(r0), ru1 = __float_as_uint(r1);
+                pm[i] = __builtin_amdgcn_perm(ru1, ru0, 0x07060302u);
+                const float q0 = r0 - __uint_as_float(ru0 & 0xffff0000u), q1 = r1 - __uint_as_float(ru1 & 0xffff0000u);
+                pl[i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+            }
+            // fragment (plane, k-group g, column) is 16 bytes = rows 8g .. 8g+7; a thread with KPT == 4 fills half of one
+            unsigned* bpu = reinterpret_cast<unsigned*>(bp);
+            const int g = ckb >> 3, sub = (ckb & 7) >> 1;
+            if constexpr (KPT == 8) {
+                ctn_lds_store16_untracked(bpu + ((0 * 2 + g) * FBN_ + ccol) * 4, u32x4{ph[0], ph[1], ph[2], ph[3]});
+                ctn_lds_store16_untracked(bpu + ((1 * 2 + g) * FBN_ + ccol) * 4, u32x4{pm[0], pm[1], pm[2], pm[3]});
+                ctn_lds_store16_untracked(bpu + ((2 * 2 + g) * FBN_ + ccol) * 4, u32x4{pl[0], pl[1], pl[2], pl[3]});
+            } else {
+                ctn_lds_store8_untracked(bpu + ((0 * 2 + g) * FBN_ + ccol) * 4 + sub, u32x2{ph[0], ph[1]});
+                ctn_lds_store8_untracked(bpu + ((1 * 2 + g) * FBN_ + ccol) * 4 + sub, u32x2{pm[0], pm[1]});
+                ctn_lds_store8_untracked(bpu + ((2 * 2 + g) * FBN_ + ccol) * 4 + sub, u32x2{pl[0], pl[1]});
+            }
+        };
+        static_assert(KPT == 8 || KPT == 4, "conversion slice");
+        auto mma = [&](const float* ap, const float* bp) {
+            const bf16x8* A8 = reinterpret_cast<const bf16x8*>(ap);
+            const bf16x8* B8 = reinterpret_cast<const bf16x8*>(bp);
+            bf16x8 bh[NJ], bm[NJ], bl[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int ix = half * FBN_ + wn0 + j * 32 + l31;
+                bh[j] = B8[ix], bm[j] = B8[2 * FBN_ + ix], bl[j] = B8[4 * FBN_ + ix];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ix = half * FBM + wm0 + i * 32 + l31;
+                const bf16x8 ah = A8[ix], am = A8[2 * FBM + ix], al = A8[4 * FBM + ix];
+#define CTN_NN_MFMA(a_, b_)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_[j], acc[i][j], 0, 0, 0)
+                CTN_NN_MFMA(al, bh);
+                CTN_NN_MFMA(ah, bl);
+                CTN_NN_MFMA(am, bm);
+                CTN_NN_MFMA(am, bh);
+                CTN_NN_MFMA(ah, bm);
+                CTN_NN_MFMA(ah, bh);
+#undef CTN_NN_MFMA
+            }
+        };
+        // Order of a wave's DMA instructions: X(0), X(1) | A(0), X(2) | A(1), X(3) | ...  Before the barrier of iteration
+        // kt everything but X(kt+2) must have landed: A(kt) for the MFMAs, X(kt+1) for the conversion.
+        issue_x(0, XLb);
+        if (nk > 1) issue_x(1, XLb + XLSZ);
+        wait_but_newest_x(nk > 1);
+        __syncthreads();          // X(0) complete; also publishes the gamma / beta rows and the epilogue's row constants
+        issue_ap(0, APb);
+        if (nk > 2) issue_x(2, XLb + 2 * XLSZ);
+        convert(XLb, BPb, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            // A(kt), X(kt+1) and the fragments of X(kt) are complete, everything of kt-1 is free.  The bare barrier
+            // instruction: __syncthreads() carries a fence that waits for ALL global-to-LDS DMA, X(kt+2) included; the
+            // waits above it are the ordering this hand-over needs, and the empty asm pins the LDS reads below it.
+            wait_but_newest_x(kt + 2 < nk);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) issue_ap(kt + 1, APb + ((kt + 1) & 1) * APSZ);
+            if (kt + 3 < nk) issue_x(kt + 3, XLb + (kt % 3) * XLSZ);
+#ifndef CTN_DBG_PREP_NO_CONVERT       // (timing builds: results are wrong)
+            if (kt + 1 < nk) convert(XLb + ((kt + 1) % 3) * XLSZ, BPb + ((kt + 1) & 1) * BPSZ, (kt + 1) * FBK);
+#endif
+#ifndef CTN_DBG_PREP_NO_MMA
+            mma(APb + (kt & 1) * APSZ, BPb + (kt & 1) * BPSZ);
+#endif
+        }
+    } else {
     issue(0, 0);
     CTN_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
@@ -714,6 +890,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
 #endif
         }
     }
+    }   // !PREP
     CTN_STAMP(3);
     __syncthreads();              // every wave is done with the tiles: reuse them as epilogue staging
     CTN_STAMP(4);
@@ -885,6 +1062,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
             atomicAdd(a.esums + ((int64_t)b * CTN_STAT_SLOTS + ctn_slot()) * 2 + tid, (double)tot);
         }
     }
+    __shared__ unsigned fin_flag;
+    if (want_stats && a.esums != nullptr)
+        ctn_finish_sums(a.fin, a.esums + (int64_t)b * CTN_STAT_SLOTS * 2, b, tiles_m * tiles_n, &fin_flag);
     CTN_STAMP(6);
 }
 
@@ -894,8 +1074,12 @@ bool fast_ok(const ctn_gemm_nn_args& a) {
 #endif
     auto al = [](const void* p) { return p == nullptr || ctn_aligned16(p); };
     if (a.M <= 64 || a.M % 4 != 0) return false;
-    if (!ctn_aligned16(a.A) || a.lda % 4 != 0) return false;
-    if (a.K1 < a.K && (!ctn_aligned16(a.A2) || a.lda2 % 4 != 0)) return false;
+    if (a.A_prep) {
+        if (!ctn_aligned16(a.A_prep) || ctn_weight_prep_bytes(a.K, a.M) >= 0x40000000) return false;
+    } else {
+        if (!ctn_aligned16(a.A) || a.lda % 4 != 0) return false;
+        if (a.K1 < a.K && (!ctn_aligned16(a.A2) || a.lda2 % 4 != 0)) return false;
+    }
     if (!ctn_aligned16(a.Y) || a.ldy % 4 != 0 || a.ybs % 4 != 0) return false;
     if (a.R && (!al(a.R) || a.ldr % 4 != 0 || a.rbs % 4 != 0 || a.ldr < a.ldy)) return false;
     if (a.Y2 && (!al(a.Y2) || a.ldy2 % 4 != 0 || a.y2bs % 4 != 0 || a.ldy2 < a.ldy)) return false;
@@ -903,8 +1087,9 @@ bool fast_ok(const ctn_gemm_nn_args& a) {
     if ((int64_t)a.K > 4096 || a.K % FBK != 0 || a.K1 % FBK != 0) return false;
     // byte offsets inside one operand (one batch item) must stay below the buffer descriptors' range
     const int64_t lim = 0x40000000 / 4 - 4096;
-    if ((int64_t)a.K * a.lda >= lim || (int64_t)a.K * a.ldx >= lim) return false;
-    if (a.K1 < a.K && ((int64_t)a.K * a.lda2 >= lim || (int64_t)a.K * a.ldxb >= lim)) return false;
+    if ((int64_t)a.K * a.ldx >= lim) return false;
+    if (!a.A_prep && (int64_t)a.K * a.lda >= lim) return false;
+    if (a.K1 < a.K && ((!a.A_prep && (int64_t)a.K * a.lda2 >= lim) || (int64_t)a.K * a.ldxb >= lim)) return false;
     if ((a.xflags & CTN_XF_NORMBWD) && (int64_t)a.K * a.ldx2 >= lim) return false;
     return true;
 }
@@ -1014,6 +1199,62 @@ int launch_fast_n(const ctn_gemm_nn_args& a, hipStream_t s) {
     return CTN_OK;
 }
 
+// Prepared-A variant.  LDS: two buffers of A fragments, two of X fragments, three landing buffers, gamma / beta rows.
+size_t prep_lds_bytes(const ctn_gemm_nn_args& a, int width) {
+    const int Kp = ctn_cdiv(a.K, FBK) * FBK;
+    const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
+    size_t floats = 2 * (size_t)(3 * 2 * FBM * 4) + 2 * (size_t)(3 * 2 * width * 4) +
+                    3 * (size_t)(FBK * width) * (bwd ? 2 : 1) + (bwd ? 1 : 2) * (size_t)Kp;
+    if (floats < (size_t)64 * width) floats = (size_t)64 * width;
+    return floats * sizeof(float);
+}
+
+template <int FBN_, int XF, bool BWD>
+int launch_prep_k(const ctn_gemm_nn_args& a, hipStream_t s) {
+    const int tiles_m = ctn_cdiv(a.M, FBM), tiles_n = ctn_cdiv(a.T, FBN_);
+    const int64_t total = (int64_t)tiles_m * tiles_n * a.batch;
+    if (total > 0x7fffffff) {
+        ctn_set_error("ctn_gemm_nn: grid too large");
+        return CTN_ERR_ARG;
+    }
+    const size_t shmem = prep_lds_bytes(a, FBN_);
+    auto kern = gemm_nn_fast_kernel<FBN_, XF, BWD, 4>;
+    if (shmem > 48 * 1024) {      // more dynamic LDS than a kernel gets by default: ask once per device
+        static bool asked[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!asked[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    120 * 1024) != hipSuccess) {
+                ctn_set_error("ctn_gemm_nn: cannot raise the dynamic LDS limit of the prepared-weight kernel");
+                return CTN_ERR_LAUNCH;
+            }
+            asked[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NTH), shmem, s, a, tiles_m, tiles_n);
+    return CTN_OK;
+}
+
+template <int FBN_>
+int launch_prep_n(const ctn_gemm_nn_args& a, hipStream_t s) {
+    if (a.xflags & CTN_XF_NORMBWD) return launch_prep_k<FBN_, 0, true>(a, s);
+    switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {
+        case 0: return launch_prep_k<FBN_, 0, false>(a, s);
+        case CTN_XF_PRELU: return launch_prep_k<FBN_, CTN_XF_PRELU, false>(a, s);
+        case CTN_XF_NORM: return launch_prep_k<FBN_, CTN_XF_NORM, false>(a, s);
+        default: return launch_prep_k<FBN_, CTN_XF_PRELU | CTN_XF_NORM, false>(a, s);
+    }
+}
+
+// Tile width of the prepared-A variant: the caller's, else 128 columns -- except with the norm-backward operand, whose
+// second landing tile would leave room for one block per CU only at that width.
+int launch_prep(const ctn_gemm_nn_args& a, hipStream_t s) {
+    const int width = (a.tile_width == 64 || a.tile_width == 128) ? a.tile_width
+                                                                  : ((a.xflags & CTN_XF_NORMBWD) ? 64 : 128);
+    return width == 128 ? launch_prep_n<128>(a, s) : launch_prep_n<64>(a, s);
+}
+
 int launch_fast(const ctn_gemm_nn_args& a, hipStream_t s) {
     return pick_fbn(a) == 128 ? launch_fast_n<128>(a, s) : launch_fast_n<64>(a, s);
 }
@@ -1043,9 +1284,13 @@ extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
     CTN_REQUIRE(a.M > 0 && a.T > 0 && a.K > 0 && a.batch > 0, "ctn_gemm_nn: empty problem");
     CTN_REQUIRE(a.arith >= CTN_ARITH_DEFAULT && a.arith <= CTN_ARITH_BF16X3, "ctn_gemm_nn: arith is one of CTN_ARITH_*");
     CTN_REQUIRE(a.tile_width == 0 || a.tile_width == 64 || a.tile_width == 128, "ctn_gemm_nn: tile_width is 0, 64 or 128");
-    CTN_REQUIRE(a.A && a.X && a.Y, "ctn_gemm_nn: null A / X / Y");
+    CTN_REQUIRE((a.A || a.A_prep) && a.X && a.Y, "ctn_gemm_nn: null A / X / Y");
     CTN_REQUIRE(a.K1 >= 0 && a.K1 <= a.K, "ctn_gemm_nn: K1 out of range");
-    CTN_REQUIRE(a.K1 == a.K || (a.A2 && a.Xb), "ctn_gemm_nn: split K needs A2 and Xb");
+    CTN_REQUIRE(a.K1 == a.K || ((a.A2 || a.A_prep) && a.Xb), "ctn_gemm_nn: split K needs A2 and Xb");
+    if (a.A_prep)
+        CTN_REQUIRE((a.arith == CTN_ARITH_DEFAULT || a.arith == CTN_ARITH_BF16X3) && fast_ok(a),
+                    "ctn_gemm_nn: a prepared A needs arith CTN_ARITH_BF16X3, M > 64, M %% 4 == 0, K %% 16 == 0, K1 %% 16 == 0, "
+                    "K <= 4096 and 16-byte aligned operands with pitches that are multiples of 4");
     CTN_REQUIRE(ctn_aligned16(a.X) && a.ldx % 4 == 0 && a.xbs % 4 == 0 && a.ldx >= a.T,
                 "ctn_gemm_nn: X must be 16-byte aligned, ldx %% 4 == 0, ldx >= T");
     if (a.K1 < a.K)
@@ -1082,11 +1327,16 @@ extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
         default:
             CTN_REQUIRE(false, "ctn_gemm_nn: unknown emode %d", a.emode);
     }
+    CTN_REQUIRE(ctn_finish_ok(a.fin) &&
+                    (!a.fin.count || ((a.emode == CTN_EPI_STATS || a.emode == CTN_EPI_NORMBWD) && a.esums && !a.ecol)),
+                "ctn_gemm_nn: fin needs a STATS / NORMBWD epilogue with esums, and out0, out1, n (COEFS: rstd)");
     const int vecA = ctn_aligned16(a.A) && a.lda % 4 == 0 &&
                      (a.K1 == a.K || (ctn_aligned16(a.A2) && a.lda2 % 4 == 0));
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (fast_ok(a))
+    if (a.A_prep)
+        rc = launch_prep(a, s);
+    else if (fast_ok(a))
         rc = launch_fast(a, s);
     else if (a.M > 64)
         rc = launch<128, 2>(a, vecA, s);

@@ -27,6 +27,11 @@ from .ops import (XF_PRELU, XF_NORM, XF_NORMBWD, EPI_STORE, EPI_STATS, EPI_HEADS
 # reading the stored one (three tensors over HBM instead of four).  False restores the reading form (diagnostics, tests).
 RECOMPUTE_DW_OUTPUT = os.environ.get("CTN_DW_RECOMPUTE", "1") != "0"
 
+# In the default arithmetic (three bf16 pieces) the weight operand of every pointwise GEMM is split once per step into
+# the matrix instruction's own layout (ops.prepared / PreparedWeights) instead of by every wave that reads it.  False
+# restores the k-major fp32 weights and the in-kernel split (diagnostics, tests); the results are bit-identical.
+USE_PREPARED_WEIGHTS = os.environ.get("CTN_PREPARED_WEIGHTS", "1") != "0"
+
 FLAT_ALIGN = 64      # floats: every tensor of a flat parameter / gradient buffer starts on a 256-byte boundary
 
 
@@ -107,6 +112,63 @@ def _flat(p):
     return None if p is None else p.detach().reshape(-1)
 
 
+def _prepared(store, key, K, M, parts, dev, K1=None):
+    """The prepared form of a K x M weight operand (parts: [(2-D source view, transpose, k_off, m_off)]) or None when
+    this arithmetic / shape does not take one.  `store` (a dict of matrices prepared earlier in the step) is used when
+    it has the key."""
+    if not (USE_PREPARED_WEIGHTS and ops.prep_usable(M, K, K1)):
+        return None
+    if store is not None and store.get(key) is not None:
+        return store[key]
+    return ops.prepared(K, M, parts, dev)
+
+
+def _layer_parts(L):
+    """key -> (K, M, K1, parts) of the four weight operands of one residual layer's GEMMs."""
+    H, Bc, Sc = L.H, L.Bc, L.Sc
+    Mo = Bc if L.dual else 0
+    W1, Ws = L.W1.view(H, Bc), L.Ws.view(Sc, H)
+    heads_f = ([(L.Wo.view(Bc, H), True, 0, 0)] if L.dual else []) + [(Ws, True, 0, Mo)]
+    heads_d = ([(L.Wo.view(Bc, H), False, 0, 0)] if L.dual else []) + [(Ws, False, Mo, 0)]
+    return {"W1f": (Bc, H, None, [(W1, True, 0, 0)]),                 # bottleneck forward: A[k = in][m = out]
+            "Hf": (H, Mo + Sc, None, heads_f),                        # both heads forward, side by side along m
+            "Hd": (Mo + Sc, H, Mo if L.dual else None, heads_d),      # both heads' input gradient, stacked along k
+            "W1d": (H, Bc, None, [(W1, False, 0, 0)])}                # bottleneck input gradient
+
+
+class PreparedWeights:
+    """Every weight operand of the separator's pointwise GEMMs in prepared form, in one bf16 buffer; refresh() splits
+    the current parameter values into it with ctn_weight_prep (a few launches) -- once per optimizer step, on the
+    stream the pass starts from.  The parameters must keep their addresses (views of a flat buffer)."""
+
+    def __init__(self, mp):
+        self.layers = [dict() for _ in mp.layers]
+        self.sep = {}
+        specs = []
+        for i, (L, _) in enumerate(mp.layers):
+            for key, (K, M, K1, parts) in _layer_parts(L).items():
+                specs.append((self.layers[i], key, K, M, K1, parts))
+        for key, (K, M, K1, parts) in _separator_parts(mp).items():
+            specs.append((self.sep, key, K, M, K1, parts))
+        specs = [sp for sp in specs if sp[3] > 64 and sp[3] % 4 == 0 and sp[2] % 16 == 0 and (sp[4] or 0) % 16 == 0]
+        total = sum(ops.weight_planes_numel(K, M) for _, _, K, M, _, _ in specs)
+        dev = mp.Wb.device
+        self.buf = torch.zeros(max(total, 8), device=dev, dtype=torch.bfloat16)
+        entries, off = [], 0
+        for store, key, K, M, K1, parts in specs:
+            n = ops.weight_planes_numel(K, M)
+            dst = self.buf[off:off + n]
+            off += n
+            store[key] = dst
+            entries += [(src, tr, ko, mo, K, M, dst) for src, tr, ko, mo in parts]
+        self._sources = [e[0] for e in entries]                   # keep the views (and their storage) alive
+        self.items = ops.wprep_items(entries) if entries else None
+
+    def refresh(self):
+        if self.items is not None:
+            ops.weight_prep(self.items)
+
+
 class Layer:
     """Detached, flattened parameter views of one ResidualBlock1d (+ its tdcn DepthwiseSeparableConv1d)."""
 
@@ -125,6 +187,7 @@ class Layer:
         self.H, self.Bc = self.W1.shape[0], self.W1.shape[1]
         self.Sc = self.Ws.shape[0]
         self.P = self.wd.shape[-1]
+        self.planes = None           # dict of prepared weight operands (PreparedWeights.layers[i]) or None
 
 
 def _pads(P, dilation, causal):
@@ -139,29 +202,40 @@ def layer_forward(L, x, skip, accumulate, dilation, causal, eps):
     dev = x.device
     H, Bc, Sc, P = L.H, L.Bc, L.Sc, L.P
     # bottleneck 1x1 + PReLU statistics
-    W1t = torch.empty((Bc, H), device=dev, dtype=torch.float32)
-    ops.transpose(L.W1.view(H, Bc), W1t, H)
+    parts = _layer_parts(L)
+    W1p = _prepared(L.planes, "W1f", *parts["W1f"][:2], parts["W1f"][3], dev)
+    W1t = None
+    if W1p is None:
+        W1t = torch.empty((Bc, H), device=dev, dtype=torch.float32)
+        ops.transpose(L.W1.view(H, Bc), W1t, H)
     y1 = new_act(B, H, T, dev)
     acc1 = Accum(B, T, causal, dev)
-    ops.gemm_nn(H, T, Bc, B, W1t, H, x, y1, bias=L.b1, emode=EPI_STATS, ealpha=L.a1, eacc=acc1)
-    st1 = ops.finalize_stats(acc1, B, H, T, eps, dev)
+    st1, fin1 = ops.stats_request(acc1, B, H, T, eps, dev)
+    ops.gemm_nn(H, T, Bc, B, W1t, H, x, y1, bias=L.b1, emode=EPI_STATS, ealpha=L.a1, eacc=acc1, A_prep=W1p, fin=fin1)
+    if st1 is None:
+        st1 = ops.finalize_stats(acc1, B, H, T, eps, dev)
     # depthwise
     y2 = new_act(B, H, T, dev)
     acc2 = Accum(B, T, causal, dev)
+    st2, fin2 = ops.stats_request(acc2, B, H, T, eps, dev)
     ops.dw_fwd(y1, L.wd.view(H, P), L.bd, y2, dilation, _pads(P, dilation, causal), xflags=XF_PRELU | XF_NORM,
-               alpha_in=L.a1, stat=st1, gamma=L.g1.view(-1), beta=L.be1.view(-1), alpha_out=L.a2, acc=acc2)
-    st2 = ops.finalize_stats(acc2, B, H, T, eps, dev)
+               alpha_in=L.a1, stat=st1, gamma=L.g1.view(-1), beta=L.be1.view(-1), alpha_out=L.a2, acc=acc2, fin=fin2)
+    if st2 is None:
+        st2 = ops.finalize_stats(acc2, B, H, T, eps, dev)
     # heads
     Mo = Bc if L.dual else 0
     Mt = Mo + Sc
-    Wct = torch.empty((H, Mt), device=dev, dtype=torch.float32)
-    if L.dual:
-        ops.transpose(L.Wo.view(Bc, H), Wct, Mt, 0)
-    ops.transpose(L.Ws.view(Sc, H), Wct, Mt, Mo)
+    Wcp = _prepared(L.planes, "Hf", *parts["Hf"][:2], parts["Hf"][3], dev)
+    Wct = None
+    if Wcp is None:
+        Wct = torch.empty((H, Mt), device=dev, dtype=torch.float32)
+        if L.dual:
+            ops.transpose(L.Wo.view(Bc, H), Wct, Mt, 0)
+        ops.transpose(L.Ws.view(Sc, H), Wct, Mt, Mo)
     out = new_act(B, Bc, T, dev) if L.dual else None
     ops.gemm_nn(Mt, T, H, B, Wct, Mt, y2, out if L.dual else skip, xflags=XF_PRELU | XF_NORM, alpha=L.a2, stat=st2,
                 gamma=L.g2.view(-1), beta=L.be2.view(-1), bias=L.bo, bias2=L.bs, emode=EPI_HEADS, Mo=Mo,
-                R=x if L.dual else None, Y2=skip, accumulate=accumulate)
+                R=x if L.dual else None, Y2=skip, accumulate=accumulate, A_prep=Wcp)
     return out, (x, y1, y2, st1, st2)
 
 
@@ -176,33 +250,42 @@ def layer_backward(L, saved, dout, dskip, sink, dilation, causal, eps):
     # heads: input gradient with the norm-2 backward sums in the epilogue
     dn2 = new_act(B, H, T, dev)
     bacc2 = Accum(B, T, causal, dev)
+    parts = _layer_parts(L)
+    finb2 = ops.coefs_request(bacc2, st2, B, H, T)
     if dual:
+        Hdp = _prepared(L.planes, "Hd", *parts["Hd"][:2], parts["Hd"][3], dev, K1=Bc)
         ops.gemm_nn(H, T, Bc + Sc, B, L.Wo.view(Bc, H), H, dout, dn2, A2=L.Ws.view(Sc, H), lda2=H, K1=Bc, Xb=dskip,
-                    emode=EPI_NORMBWD, E=y2, ealpha=L.a2, estat=st2, egamma=L.g2.view(-1), eacc=bacc2)
+                    emode=EPI_NORMBWD, E=y2, ealpha=L.a2, estat=st2, egamma=L.g2.view(-1), eacc=bacc2, A_prep=Hdp,
+                    fin=finb2)
         ops.gemm_nt(Bc + Sc, H, T, B, dout, y2, sink.g(o["Wo"]).view(Bc, H), H, Ab=dskip, M1=Bc,
                     C2=sink.g(o["Ws"]).view(Sc, H), ldc2=H, a_rowsum=sink.g(o["bo"]), a_rowsum2=sink.g(o["bs"]),
                     bflags=XF_PRELU | XF_NORM, b_alpha=L.a2, b_stat=st2, b_gamma=L.g2.view(-1), b_beta=L.be2.view(-1))
     else:
+        # (a dual layer that received no residual gradient: its prepared matrix stacks both heads and does not apply)
+        Hdp = None if L.dual else _prepared(L.planes, "Hd", *parts["Hd"][:2], parts["Hd"][3], dev)
         ops.gemm_nn(H, T, Sc, B, L.Ws.view(Sc, H), H, dskip, dn2, emode=EPI_NORMBWD, E=y2, ealpha=L.a2, estat=st2,
-                    egamma=L.g2.view(-1), eacc=bacc2)
+                    egamma=L.g2.view(-1), eacc=bacc2, A_prep=Hdp, fin=finb2)
         ops.gemm_nt(Sc, H, T, B, dskip, y2, sink.g(o["Ws"]).view(Sc, H), H, a_rowsum=sink.g(o["bs"]),
                     bflags=XF_PRELU | XF_NORM, b_alpha=L.a2, b_stat=st2, b_gamma=L.g2.view(-1), b_beta=L.be2.view(-1))
-        if L.dual:   # the residual head exists but received no gradient
-            pass
-    ops.bwd_coefs(bacc2, st2, B, H, T, eps)
+    if finb2 is None:
+        ops.bwd_coefs(bacc2, st2, B, H, T, eps)
     # depthwise backward (+ norm-2 / PReLU-2 backward on load, norm-1 sums on the way out)
     dn1 = new_act(B, H, T, dev)
     bacc1 = Accum(B, T, causal, dev)
+    finb1 = ops.coefs_request(bacc1, st1, B, H, T)
     ops.dw_bwd(dn2, y1, L.wd.view(H, P), sink.g(o["wd"]).view(H, P), sink.g(o["bd"]), dn1, dilation,
                _pads(P, dilation, causal), xflags=XF_PRELU | XF_NORM, alpha1=L.a1, stat1=st1, gamma1=L.g1.view(-1),
                beta1=L.be1.view(-1), dgamma1=sink.g(o["g1"]).view(-1), dbeta1=sink.g(o["be1"]).view(-1), iacc=bacc1,
                y2=y2, alpha2=L.a2, stat2=st2, gamma2=L.g2.view(-1), dgamma2=sink.g(o["g2"]).view(-1),
-               dbeta2=sink.g(o["be2"]).view(-1), dalpha2=sink.alpha_slot(o["a2"]), bias=L.bd, recompute_y2=RECOMPUTE_DW_OUTPUT)
-    ops.bwd_coefs(bacc1, st1, B, H, T, eps)
+               dbeta2=sink.g(o["be2"]).view(-1), dalpha2=sink.alpha_slot(o["a2"]), bias=L.bd, recompute_y2=RECOMPUTE_DW_OUTPUT,
+               fin=finb1)
+    if finb1 is None:
+        ops.bwd_coefs(bacc1, st1, B, H, T, eps)
     # bottleneck: input gradient (+ residual path) and weight gradient, norm-1 / PReLU-1 backward on load
     dx = new_act(B, Bc, T, dev)
+    W1dp = _prepared(L.planes, "W1d", *parts["W1d"][:2], parts["W1d"][3], dev)
     ops.gemm_nn(Bc, T, H, B, L.W1.view(H, Bc), Bc, dn1, dx, xflags=XF_NORMBWD, X2=y1, alpha=L.a1, stat=st1,
-                gamma=L.g1.view(-1), emode=EPI_ADD, R=dout if dual else None)
+                gamma=L.g1.view(-1), emode=EPI_ADD, R=dout if dual else None, A_prep=W1dp)
     ops.gemm_nt(H, Bc, T, B, dn1, x, sink.g(o["W1"]).view(H, Bc), Bc, aflags=XF_NORMBWD, A2=y1, a_alpha=L.a1,
                 a_stat=st1, a_gamma=L.g1.view(-1), a_rowsum=sink.g(o["b1"]), a_dalpha=sink.alpha_slot(o["a1"]))
     return dx
@@ -363,10 +446,14 @@ class Conv1x1Fn(torch.autograd.Function):
         x = as_act(x.detach())
         B, K, T = x.shape
         M = weight.shape[0]
-        Wt = torch.empty((K, M), device=x.device, dtype=torch.float32)
-        ops.transpose(weight.detach().view(M, K), Wt, M)
+        w2 = weight.detach().view(M, K)
+        Wp = _prepared(None, None, K, M, [(w2, True, 0, 0)], x.device)
+        Wt = None
+        if Wp is None:
+            Wt = torch.empty((K, M), device=x.device, dtype=torch.float32)
+            ops.transpose(w2, Wt, M)
         y = new_act(B, M, T, x.device)
-        ops.gemm_nn(M, T, K, B, Wt, M, x, y, bias=None if bias is None else bias.detach())
+        ops.gemm_nn(M, T, K, B, Wt, M, x, y, bias=None if bias is None else bias.detach(), A_prep=Wp)
         ctx.saved = (x, weight, bias)
         return y
 
@@ -377,7 +464,8 @@ class Conv1x1Fn(torch.autograd.Function):
         M = weight.shape[0]
         dy = as_act(dy)
         dx = new_act(B, K, T, x.device)
-        ops.gemm_nn(K, T, M, B, weight.detach().view(M, K), K, dy, dx)
+        w2 = weight.detach().view(M, K)
+        ops.gemm_nn(K, T, M, B, w2, K, dy, dx, A_prep=_prepared(None, None, M, K, [(w2, False, 0, 0)], x.device))
         dW = torch.zeros((M, K), device=x.device, dtype=torch.float32)
         db = None if bias is None else torch.zeros((M,), device=x.device, dtype=torch.float32)
         ops.gemm_nt(M, K, T, B, dy, x, dW, K, a_rowsum=db)
@@ -528,6 +616,22 @@ class ModelParams:
                 n = len(Layer.NAMES_DUAL if dual else Layer.NAMES_SINGLE)
                 self.layers.append((Layer([next(it) for _ in range(n)], dual), 2 ** l))
         self.a_sep, self.Wm, self.bm, self.dec_W = (next(it) for _ in range(4))
+        self.planes = None
+        store = cfg.get("weight_planes")
+        if store is not None:                  # a PreparedWeights over these very parameters, refreshed this step
+            self.planes = store.sep
+            for (L, _), d in zip(self.layers, store.layers):
+                L.planes = d
+
+
+def _separator_parts(mp):
+    """key -> (K, M, K1, parts) of the weight operands of the separator's own GEMMs (bottleneck and mask convolution,
+    forward and input gradient)."""
+    Bc, N = mp.Wb.shape[0], mp.Wb.shape[1]
+    Mm, Sc = mp.Wm.shape[0], mp.Wm.shape[1]
+    Wb, Wm = mp.Wb.detach().view(Bc, N), mp.Wm.detach().view(Mm, Sc)
+    return {"Wbf": (N, Bc, None, [(Wb, True, 0, 0)]), "Wbd": (Bc, N, None, [(Wb, False, 0, 0)]),
+            "Wmf": (Sc, Mm, None, [(Wm, True, 0, 0)]), "Wmd": (Mm, Sc, None, [(Wm, False, 0, 0)])}
 
 
 def separator_forward(mp, w, st0_acc, eps, sigmoid=True):
@@ -539,11 +643,15 @@ def separator_forward(mp, w, st0_acc, eps, sigmoid=True):
     dev = w.device
     Bc = mp.Wb.shape[0]
     st0 = ops.finalize_stats(st0_acc, B, N, T, eps, dev)
-    Wbt = torch.empty((N, Bc), device=dev, dtype=torch.float32)
-    ops.transpose(mp.Wb.detach().view(Bc, N), Wbt, Bc)
+    sparts = _separator_parts(mp)
+    Wbp = _prepared(mp.planes, "Wbf", *sparts["Wbf"][:2], sparts["Wbf"][3], dev)
+    Wbt = None
+    if Wbp is None:
+        Wbt = torch.empty((N, Bc), device=dev, dtype=torch.float32)
+        ops.transpose(mp.Wb.detach().view(Bc, N), Wbt, Bc)
     x = new_act(B, Bc, T, dev)
     ops.gemm_nn(Bc, T, N, B, Wbt, Bc, w, x, xflags=XF_NORM, stat=st0, gamma=mp.g0.detach().view(-1),
-                beta=mp.be0.detach().view(-1), bias=mp.bb.detach())
+                beta=mp.be0.detach().view(-1), bias=mp.bb.detach(), A_prep=Wbp)
     Sc = mp.layers[0][0].Sc
     skip = new_act(B, Sc, T, dev)
     saved_layers = []
@@ -552,11 +660,14 @@ def separator_forward(mp, w, st0_acc, eps, sigmoid=True):
         saved_layers.append(sv)
         x = x_next
     M = mp.Wm.shape[0]
-    Wmt = torch.empty((Sc, M), device=dev, dtype=torch.float32)
-    ops.transpose(mp.Wm.detach().view(M, Sc), Wmt, M)
+    Wmp = _prepared(mp.planes, "Wmf", *sparts["Wmf"][:2], sparts["Wmf"][3], dev)
+    Wmt = None
+    if Wmp is None:
+        Wmt = torch.empty((Sc, M), device=dev, dtype=torch.float32)
+        ops.transpose(mp.Wm.detach().view(M, Sc), Wmt, M)
     mask = new_act(B, M, T, dev)
     ops.gemm_nn(M, T, Sc, B, Wmt, M, skip, mask, xflags=XF_PRELU, alpha=mp.a_sep.detach(), bias=mp.bm.detach(),
-                emode=EPI_SIGMOID if sigmoid else EPI_STORE)
+                emode=EPI_SIGMOID if sigmoid else EPI_STORE, A_prep=Wmp)
     return mask, (st0, skip, saved_layers)
 
 
@@ -575,8 +686,10 @@ def separator_backward(mp, w, saved, dz, sink, eps):
     ops.gemm_nt(M, Sc, T, B, dz, skip, sink.g(mp.Wm).view(M, Sc), Sc, a_rowsum=sink.g(mp.bm), bflags=XF_PRELU,
                 b_alpha=mp.a_sep.detach())
     dskip = new_act(B, Sc, T, dev)
+    sparts = _separator_parts(mp)
     ops.gemm_nn(Sc, T, M, B, mp.Wm.detach().view(M, Sc), Sc, dz, dskip, emode=EPI_PRELUBWD, E=skip,
-                ealpha=mp.a_sep.detach(), esums=sink.alpha_slot(mp.a_sep))
+                ealpha=mp.a_sep.detach(), esums=sink.alpha_slot(mp.a_sep),
+                A_prep=_prepared(mp.planes, "Wmd", *sparts["Wmd"][:2], sparts["Wmd"][3], dev))
     dout = None
     # cfg["region_hook"](layer index): called after the backward of layer `index` has been enqueued, for the indices in
     # cfg["region_layers"] -- the first layer of every TCN block but block 0.  Everything behind that layer in the
@@ -591,11 +704,14 @@ def separator_backward(mp, w, saved, dz, sink, eps):
     # separator bottleneck
     dn0 = new_act(B, N, T, dev)
     bacc0 = Accum(B, T, causal, dev)
+    fin0 = ops.coefs_request(bacc0, st0, B, N, T)
     ops.gemm_nn(N, T, Bc, B, mp.Wb.detach().view(Bc, N), N, dout, dn0, emode=EPI_NORMBWD, E=w, ealpha=None,
-                estat=st0, egamma=mp.g0.detach().view(-1), eacc=bacc0)
+                estat=st0, egamma=mp.g0.detach().view(-1), eacc=bacc0, fin=fin0,
+                A_prep=_prepared(mp.planes, "Wbd", *sparts["Wbd"][:2], sparts["Wbd"][3], dev))
     ops.gemm_nt(Bc, N, T, B, dout, w, sink.g(mp.Wb).view(Bc, N), N, a_rowsum=sink.g(mp.bb), bflags=XF_NORM,
                 b_stat=st0, b_gamma=mp.g0.detach().view(-1), b_beta=mp.be0.detach().view(-1))
-    ops.bwd_coefs(bacc0, st0, B, N, T, eps)
+    if fin0 is None:
+        ops.bwd_coefs(bacc0, st0, B, N, T, eps)
     return dn0, st0
 
 

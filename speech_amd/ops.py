@@ -127,24 +127,61 @@ def zeros(shape, device, dtype):
 def accum_bytes(B, T, cln):
     """Arena bytes of one Accum (see ZeroArena.take's rounding)."""
     n = B * 2 * round4(T) * 4 if cln else B * _lib.STAT_SLOTS * 2 * 8
-    return (n + 255) // 256 * 256
+    extra = 0 if cln else (B * 4 + 255) // 256 * 256              # the gLN accumulator's ticket counters
+    return (n + 255) // 256 * 256 + extra
 
 
 class Accum:
     """Zeroed accumulators for one norm's statistics: double (B, STAT_SLOTS, 2) for gLN (slot-replicated, the
     value is the sum over slots), float (B, 2, ld) for cLN."""
 
-    __slots__ = ("sums", "col", "ld")
+    __slots__ = ("sums", "col", "ld", "count")
 
     def __init__(self, B, T, cln, device):
         if cln:
             self.ld = round4(T)
             self.col = zeros((B, 2, self.ld), device, torch.float32)
-            self.sums = None
+            self.sums = self.count = None
         else:
             self.ld = 0
             self.col = None
             self.sums = zeros((B, _lib.STAT_SLOTS, 2), device, torch.float64)
+            self.count = zeros((B,), device, torch.int32)         # one ticket per producing block (ctn_finish)
+
+
+# A producer of gLN sums can finish the reduction itself (ctn_finish in include/ctn.h): the block that adds the last
+# partial sums writes mean / rstd (or the backward coefficients), and the stand-alone finalize launch disappears.
+# CTN_FOLD_FINISH=0 keeps the stand-alone launches (diagnostics, tests).
+FOLD_FINISH = os.environ.get("CTN_FOLD_FINISH", "1") != "0"
+
+
+def stats_request(acc, B, Cc, T, eps, device):
+    """(stat, fin) for a producer about to fill `acc` with forward statistics: fin goes to the producer's `fin=`
+    argument and stat is complete when the producer has run; (None, None) when the reduction cannot be finished in
+    the producer (cLN, or switched off) -- call finalize_stats() behind the producer then."""
+    if not FOLD_FINISH or acc.sums is None:
+        return None, None
+    stat = Stat(torch.empty((B,), device=device, dtype=torch.float32),
+                torch.empty((B,), device=device, dtype=torch.float32), 1, 0, False)
+    return stat, (_lib.FIN_STATS, acc, stat.mean, stat.rstd, None, float(Cc) * float(T), eps)
+
+
+def coefs_request(acc, stat, B, Cc, T):
+    """fin for a producer about to fill `acc` with the backward sums of `stat`'s norm: stat.c1 / stat.c2 are complete
+    when the producer has run.  None when not possible: call bwd_coefs() behind the producer then."""
+    if not FOLD_FINISH or acc.sums is None or stat.cln:
+        return None
+    stat.c1 = torch.empty_like(stat.mean)
+    stat.c2 = torch.empty_like(stat.mean)
+    return (_lib.FIN_COEFS, acc, stat.c1, stat.c2, stat.rstd, float(Cc) * float(T), 0.0)
+
+
+def _set_fin(fin_struct, fin):
+    if fin is None:
+        return
+    kind, acc, out0, out1, rstd, n, eps = fin
+    fin_struct.count, fin_struct.out0, fin_struct.out1 = _ptr(acc.count), _ptr(out0), _ptr(out1)
+    fin_struct.rstd, fin_struct.n, fin_struct.eps, fin_struct.kind = _ptr(rstd), n, eps, kind
 
 
 # ------------------------------------------------------------------------------------------------ arithmetic mode
@@ -252,6 +289,45 @@ def transpose(src2d, dst, ldd, coff=0):
     _lib.check(lib.ctn_transpose(_ptr(src2d), M, K, _ptr(dst), ldd, coff, _stream()), "ctn_transpose")
 
 
+def prep_usable(M, K, K1=None):
+    """True when ctn_gemm_nn takes a prepared A for this shape in the current arithmetic (three bf16 pieces)."""
+    K1 = K if K1 is None else K1
+    return _gemm_split == 3 and M > 64 and M % 4 == 0 and K % 16 == 0 and K1 % 16 == 0 and K <= 4096
+
+
+def weight_planes_numel(K, M):
+    """bf16 elements of a prepared K x M matrix (three planes, K padded to 16, M to 128)."""
+    return 3 * ((K + 15) // 16 * 16) * ((M + 127) // 128 * 128)
+
+
+def wprep_items(entries):
+    """ctypes array of ctn_wprep_item from (src2d, transpose, k_off, m_off, K, M, dst) tuples; src2d a (rows, cols) fp32
+    view with unit column stride, dst the prepared matrix (bf16 tensor of weight_planes_numel(K, M) elements, zero
+    where no item writes).  The array holds raw addresses: the caller keeps the tensors alive."""
+    arr = (_lib.WPrepItem * len(entries))()
+    for it, (src, transpose, k_off, m_off, K, M, dst) in zip(arr, entries):
+        _require_cuda(src, dst)
+        assert src.dim() == 2 and src.dtype == torch.float32 and src.stride(1) == 1
+        assert dst.dtype == torch.bfloat16 and dst.is_contiguous() and dst.numel() >= weight_planes_numel(K, M)
+        it.src, it.ld, it.dst = _ptr(src), src.stride(0), _ptr(dst)
+        it.rows, it.cols, it.transpose = src.shape[0], src.shape[1], 1 if transpose else 0
+        it.k_off, it.m_off, it.K, it.M = k_off, m_off, K, M
+    return arr
+
+
+def weight_prep(items):
+    """Runs ctn_weight_prep over a wprep_items() array on the current stream."""
+    lib = _lib.load()
+    _lib.check(lib.ctn_weight_prep(items, len(items), _stream()), "ctn_weight_prep")
+
+
+def prepared(K, M, parts, device):
+    """A freshly prepared K x M matrix from parts = [(src2d, transpose, k_off, m_off), ...]."""
+    dst = torch.zeros(weight_planes_numel(K, M), device=device, dtype=torch.bfloat16)
+    weight_prep(wprep_items([(src, tr, ko, mo, K, M, dst) for src, tr, ko, mo in parts]))
+    return dst
+
+
 def norm_stats(x, alpha, acc):
     lib = _lib.load()
     B, Cc, T = x.shape
@@ -319,8 +395,10 @@ def norm_bwd_apply(dn, x, alpha, stat, gamma, dx, dalpha):
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, xflags=0, X2=None, alpha=None,
             stat=None, gamma=None, beta=None, bias=None, bias2=None, emode=EPI_STORE, Mo=0, R=None, Y2=None,
-            accumulate=False, ealpha=None, eacc=None, E=None, estat=None, egamma=None, esums=None, tile_width=0):
-    """Y[b] = A(k-major) . xform(X[b]); see ctn_gemm_nn in include/ctn.h.  X/Xb/X2/Y/Y2/R/E are act views."""
+            accumulate=False, ealpha=None, eacc=None, E=None, estat=None, egamma=None, esums=None, tile_width=0,
+            A_prep=None, fin=None):
+    """Y[b] = A(k-major) . xform(X[b]); see ctn_gemm_nn in include/ctn.h.  X/Xb/X2/Y/Y2/R/E are act views.  A_prep: the
+    same A as a prepared matrix (prepared() / weight_prep()); A, A2 may then be None."""
     lib = _lib.load()
     a = _lib.GemmNNArgs()
     a.tile_width = tile_width or _gemm_tile
@@ -359,6 +437,8 @@ def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, 
     if estat is not None:
         a.emean, a.erstd, a.essb, a.esst = _ptr(estat.mean), _ptr(estat.rstd), estat.sb, estat.st
     a.egamma = _ptr(egamma)
+    a.A_prep = _ptr(A_prep)
+    _set_fin(a.fin, fin)
     _lib.check(lib.ctn_gemm_nn(C.byref(a), _stream()), "ctn_gemm_nn")
 
 
@@ -413,7 +493,7 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
 
 # ------------------------------------------------------------------------------------------------ depthwise
 def dw_fwd(x, w, bias, y, dilation, pad_left, *, xflags=0, alpha_in=None, stat=None, gamma=None, beta=None,
-           alpha_out=None, acc=None, stats=True):
+           alpha_out=None, acc=None, stats=True, fin=None):
     lib = _lib.load()
     B, Cc, T = x.shape
     a = _lib.DwFwdArgs()
@@ -431,12 +511,13 @@ def dw_fwd(x, w, bias, y, dilation, pad_left, *, xflags=0, alpha_in=None, stat=N
         a.alpha_out = _ptr(alpha_out)
         a.esums = _ptr(acc.sums)
         a.ecol, a.ecol_ld = _ptr(acc.col), acc.ld
+    _set_fin(a.fin, fin)
     _lib.check(lib.ctn_dw_fwd(C.byref(a), _stream()), "ctn_dw_fwd")
 
 
 def dw_bwd(dn2, x, w, dw, dbias, dx, dilation, pad_left, *, xflags=0, alpha1=None, stat1=None, gamma1=None,
            beta1=None, dgamma1=None, dbeta1=None, iacc=None, y2=None, alpha2=None, stat2=None, gamma2=None,
-           dgamma2=None, dbeta2=None, dalpha2=None, bias=None, recompute_y2=False):
+           dgamma2=None, dbeta2=None, dalpha2=None, bias=None, recompute_y2=False, fin=None):
     lib = _lib.load()
     B, Cc, T = x.shape
     a = _lib.DwBwdArgs()
@@ -468,6 +549,7 @@ def dw_bwd(dn2, x, w, dw, dbias, dx, dilation, pad_left, *, xflags=0, alpha1=Non
     # the library needs y2 for every other launch, so it is passed whenever there is one
     rows_fit = T <= 4096 and w.shape[-1] <= 4 and not cln and stat1 is not None and stat2 is not None
     a.bias, a.recompute_y2 = _ptr(bias), 1 if (recompute_y2 and rows_fit) else 0
+    _set_fin(a.fin, fin)
     _lib.check(lib.ctn_dw_bwd(C.byref(a), _stream()), "ctn_dw_bwd")
 
 

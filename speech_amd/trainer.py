@@ -12,7 +12,8 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .functional import ConvTasNetFn, flat_layout
+from . import functional
+from .functional import ConvTasNetFn, ModelParams, PreparedWeights, flat_layout
 
 
 def allreduce_flat(flat, n_buckets=1, group=None):
@@ -97,6 +98,8 @@ class FlatTrainer:
         self.v = torch.zeros_like(self.flat_p)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.step_count = 0
+        # weight operands of the pointwise GEMMs in prepared form (default arithmetic): one buffer, refreshed per pass
+        self._prepared = PreparedWeights(ModelParams(self.params, model.fused_config()))
         if self.world > 1:                         # identical replicas: broadcast rank 0's weights
             dist.broadcast(self.flat_p, src=0, group=self.group)
 
@@ -206,10 +209,15 @@ class FlatTrainer:
         regions = self._region_table() if overlap else []
         hook_layers = {first: k for k, (first, _, _, _) in enumerate(regions) if first is not None}
         self._exchanged = False
+        planes = None
+        if functional.USE_PREPARED_WEIGHTS and ops.get_gemm_split() == 3:
+            self._prepared.refresh()               # on the stream every sub-batch stream waits for below
+            planes = self._prepared
         if n == 1:
             main = torch.cuda.current_stream()
             cfg = self.model.fused_config()
             cfg["grad_flat"], cfg["grad_detached"] = self.flat_g, True
+            cfg["weight_planes"] = planes
             if overlap:
                 def hook(layer, sink):
                     _, start, end, first_param = regions[hook_layers[layer]]
@@ -240,6 +248,7 @@ class FlatTrainer:
             with torch.cuda.stream(st):
                 cfg = self.model.fused_config()
                 cfg["grad_flat"], cfg["grad_zero"], cfg["grad_detached"] = self.flat_g, False, True
+                cfg["weight_planes"] = planes
                 if overlap:
                     # every sub-batch folds its own slope gradients when it closes a region; the region is exchanged
                     # when the LAST sub-batch has closed it (the host enqueues the sub-batches one after the other, so

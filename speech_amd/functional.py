@@ -27,10 +27,12 @@ from .ops import (XF_PRELU, XF_NORM, XF_NORMBWD, EPI_STORE, EPI_STATS, EPI_HEADS
 # reading the stored one (three tensors over HBM instead of four).  False restores the reading form (diagnostics, tests).
 RECOMPUTE_DW_OUTPUT = os.environ.get("CTN_DW_RECOMPUTE", "1") != "0"
 
-# In the default arithmetic (three bf16 pieces) the weight operand of every pointwise GEMM is split once per step into
-# the matrix instruction's own layout (ops.prepared / PreparedWeights) instead of by every wave that reads it.  False
-# restores the k-major fp32 weights and the in-kernel split (diagnostics, tests); the results are bit-identical.
-USE_PREPARED_WEIGHTS = os.environ.get("CTN_PREPARED_WEIGHTS", "1") != "0"
+# In the default arithmetic (three bf16 pieces) the weight operand of every pointwise GEMM can be split once per step
+# into the matrix instruction's own layout (ops.prepared / PreparedWeights) instead of by every wave that reads it; the
+# results are bit-identical and a pass has 70 launches fewer (no weight transposes).  Off by default: at the benchmark's
+# batch the prepared-operand kernel, which holds two blocks per CU where the in-kernel split holds three, is 8 % slower
+# on the 512-row shapes.  CTN_PREPARED_WEIGHTS=1 switches it on.
+USE_PREPARED_WEIGHTS = os.environ.get("CTN_PREPARED_WEIGHTS", "0") != "0"
 
 FLAT_ALIGN = 64      # floats: every tensor of a flat parameter / gradient buffer starts on a 256-byte boundary
 

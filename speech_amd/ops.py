@@ -150,9 +150,12 @@ class Accum:
 
 
 # A producer of gLN sums can finish the reduction itself (ctn_finish in include/ctn.h): the block that adds the last
-# partial sums writes mean / rstd (or the backward coefficients), and the stand-alone finalize launch disappears.
-# CTN_FOLD_FINISH=0 keeps the stand-alone launches (diagnostics, tests).
-FOLD_FINISH = os.environ.get("CTN_FOLD_FINISH", "1") != "0"
+# partial sums writes mean / rstd (or the backward coefficients), and the stand-alone finalize launch disappears (98
+# launches of a training pass).  Off by default: a block must see its additions performed before it takes its ticket, and
+# that wait also covers the block's output stores, which it otherwise leaves in flight when it retires -- the depthwise
+# kernels run at less than half their rate that way (85 -> 202 us per launch at batch 32).  CTN_FOLD_FINISH=1 switches
+# it on (it pays where a pass is bound by its launch count).
+FOLD_FINISH = os.environ.get("CTN_FOLD_FINISH", "0") != "0"
 
 
 def stats_request(acc, B, Cc, T, eps, device):

@@ -13,6 +13,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def fold_on():
+    from speech_amd import ops
+    before = ops.FOLD_FINISH
+    ops.FOLD_FINISH = True
+    yield
+    ops.FOLD_FINISH = before
+
+
 def rnd(shape, seed, scale=1.0):
     return (synth.normal(shape, seed) * scale).float().to(dev())
 
@@ -120,6 +129,6 @@ def test_whole_network_gradients_do_not_depend_on_where_the_reductions_finish():
             torch.cuda.synchronize()
             outs.append((loss.item(), tr.flat_g.clone()))
         finally:
-            ops.FOLD_FINISH = True
+            ops.FOLD_FINISH = True            # (the fixture restores the module's own default)
     assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * max(1.0, abs(outs[1][0]))
     assert_close(outs[0][1], outs[1][1], 2e-5, "flat gradient")

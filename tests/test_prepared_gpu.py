@@ -241,6 +241,7 @@ def test_trainer_gradients_agree_with_and_without_prepared_weights():
     mix, src = synth.make_batch(2, 2, 8000, 5)
     mix, src = mix.to(dev()), src.to(dev())
     outs = []
+    before = functional.USE_PREPARED_WEIGHTS
     for use in (True, False):
         functional.USE_PREPARED_WEIGHTS = use
         try:
@@ -251,6 +252,6 @@ def test_trainer_gradients_agree_with_and_without_prepared_weights():
             torch.cuda.synchronize()
             outs.append((loss.item(), tr.flat_g.clone()))
         finally:
-            functional.USE_PREPARED_WEIGHTS = True
+            functional.USE_PREPARED_WEIGHTS = before
     assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * max(1.0, abs(outs[1][0]))
     assert_close(outs[0][1], outs[1][1], 2e-5, "flat gradient")

@@ -112,6 +112,14 @@ def test_e2e_paper_golden(golden):
     _e2e(golden, "e2e_paper", O.CONFIG_PAPER, False)
 
 
+def test_e2e_paper_causal3_golden(golden):
+    _e2e(golden, "e2e_paper_causal3", O.CONFIG_CAUSAL3, False)
+
+
+def test_e2e_paper_causal3_full_length_golden(golden):
+    _e2e(golden, "e2e_paper_causal3_full", O.CONFIG_CAUSAL3, False)
+
+
 def test_parameter_shapes_paper():
     shapes = O.parameter_shapes(O.CONFIG_PAPER)
     assert len(shapes) == 343

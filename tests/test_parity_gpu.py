@@ -196,6 +196,11 @@ def test_e2e_paper_causal3_golden(golden):
     _e2e(golden, "e2e_paper_causal3", O.CONFIG_CAUSAL3, False)
 
 
+def test_e2e_paper_causal3_full_length_golden(golden):
+    """Causal 3-speaker network at paper width on a full 4 s mixture (the other causal fixture holds 2 s)."""
+    _e2e(golden, "e2e_paper_causal3_full", O.CONFIG_CAUSAL3, False)
+
+
 def test_train_two_steps_golden(golden):
     """FlatTrainer (fused clip + Adam on flat buffers) against the reference's post-step parameters."""
     from speech_amd.criterion.pit import PIT1d
@@ -303,32 +308,51 @@ def test_extract_latent_matches_forward():
         assert_grad_close(p.grad, gr, "modular grad " + k)
 
 
-def test_full_size_properties():
-    """Paper config at the benchmark's full size (batch 4, 4 s): size-independent properties."""
+@pytest.mark.parametrize("cfg_name", ["paper", "causal3"])
+def test_full_size_properties(cfg_name):
+    """Paper width at the benchmark's full size (batch 4, 4 s), two speakers with the global norm and three speakers
+    with the cumulative (causal) norm: size-independent properties."""
     from speech_amd.criterion.pit import PIT1d
     from speech_amd.criterion.sdr import NegSISDR
-    cfg = O.CONFIG_PAPER
+    cfg = {"paper": O.CONFIG_PAPER, "causal3": O.CONFIG_CAUSAL3}[cfg_name]
+    S = cfg["n_sources"]
     model = load_state(build(cfg), cases.e2e_state(cfg))
-    crit = PIT1d(NegSISDR(), 2)
+    crit = PIT1d(NegSISDR(), S)
     mixture, sources = cases.e2e_batch(cfg, 4, 32000, 3)
     mixture, sources = mixture.to(dev()), sources.to(dev())
     out = model(mixture)
     loss, perm = crit(out, sources)
-    assert out.shape == (4, 2, 32000) and torch.isfinite(out).all()
+    assert out.shape == (4, S, 32000) and torch.isfinite(out).all()
     # determinism of the forward (no atomics on the forward data path other than statistics)
     out2 = model(mixture)
     assert_close(out2, out, 1e-6, "forward repeatability")
     # batch independence: every op on the path is per-utterance
     out_single = model(mixture[1:2])
     assert_close(out_single, out[1:2], 1e-5, "batch independence")
-    # permutation equivariance of PIT: swapping the targets swaps the chosen permutation, same loss
-    loss_s, perm_s = crit(out, sources[:, [1, 0]])
-    assert_close(loss_s, loss, 1e-6, "PIT loss under target swap")
-    assert torch.equal(perm_s, 1 - perm)
+    # permutation equivariance of PIT: reordering the targets reorders the chosen assignment, same loss.  perm[b][i] is
+    # the target matched to estimate i; with targets' = targets[:, order] the same pairing reads order^-1[perm].
+    order = list(range(1, S)) + [0]
+    inverse = torch.tensor([order.index(j) for j in range(S)], device=perm.device)
+    loss_s, perm_s = crit(out, sources[:, order])
+    assert_close(loss_s, loss, 1e-6, "PIT loss under a reordering of the targets")
+    assert torch.equal(perm_s, inverse[perm])
     # SI-SDR is invariant to the scale of the estimate
     loss_k, perm_k = crit(out * 3.0, sources)
     assert_close(loss_k, loss, 1e-5, "scale invariance")
     assert torch.equal(perm_k, perm)
+    if cfg["causal"]:
+        # causality: the first 2 s of the output do not depend on the last 2 s of the input (whole encoder frames)
+        cut = 16000
+        later = mixture.clone()
+        later[..., cut:] = 0.0
+        out_c = model(later)
+        safe = cut - cfg["kernel_size"]
+        assert_close(out_c[..., :safe], out[..., :safe], 1e-5, "causality")
+    # one backward pass at this size leaves finite gradients everywhere
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
 def test_paper_backward_is_reproducible():

@@ -208,6 +208,9 @@ def gen_e2e(name, cfg, batch, T, steps, full):
 def main():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import convtasnet_oracle as O
+    if "--causal3-full" in sys.argv:      # only the full-length causal fixture (the others are unchanged)
+        gen_e2e("e2e_paper_causal3_full", O.CONFIG_CAUSAL3, batch=1, T=32000, steps=1, full=False)
+        return
     gen_norm()
     gen_resblock()
     gen_pit()
@@ -216,6 +219,7 @@ def main():
     gen_e2e("e2e_small_causal3", small_c3, batch=2, T=8003, steps=2, full=True)
     gen_e2e("e2e_paper", O.CONFIG_PAPER, batch=1, T=32000, steps=1, full=False)
     gen_e2e("e2e_paper_causal3", O.CONFIG_CAUSAL3, batch=1, T=16000, steps=1, full=False)
+    gen_e2e("e2e_paper_causal3_full", O.CONFIG_CAUSAL3, batch=1, T=32000, steps=1, full=False)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

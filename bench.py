@@ -149,23 +149,25 @@ def device_2r1w_rate(device):
     return _probe_rate(device, True)
 
 
-def mfma_bare_loop_rate(device, iters=20000):
-    """TFLOP/s of v_mfma_f32_32x32x2_f32 issued back to back from registers on random operands by every SIMD of the
-    chip (four waves per SIMD, four independent accumulators per wave): the f32 matrix rate this GPU sustains with no
-    memory, LDS or vector work in the way."""
+def mfma_bare_loop_rate(device, iters=20000, bf16=False):
+    """TFLOP/s of v_mfma_f32_32x32x2_f32 (bf16: v_mfma_f32_32x32x16_bf16) issued back to back from registers on random
+    operands by every SIMD of the chip (four waves per SIMD, four independent accumulators per wave): the matrix rate
+    this GPU sustains with no memory, LDS or vector work in the way."""
     from speech_amd import _lib
     lib = _lib.load()
+    fn, name, flops = ((lib.ctn_probe_mfma_bf16, "ctn_probe_mfma_bf16", 32768) if bf16 else
+                       (lib.ctn_probe_mfma_f32, "ctn_probe_mfma_f32", 4096))
     blocks = 256 * 4
     src = torch.empty(65536, device=device, dtype=torch.float32).normal_()
     out = torch.empty(blocks * 256, device=device, dtype=torch.float32)
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.ctn_probe_mfma_f32(src.data_ptr(), out.data_ptr(), blocks, 200, stream), "ctn_probe_mfma_f32")
+    _lib.check(fn(src.data_ptr(), out.data_ptr(), blocks, 200, stream), name)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(lib.ctn_probe_mfma_f32(src.data_ptr(), out.data_ptr(), blocks, iters, stream), "ctn_probe_mfma_f32")
+    _lib.check(fn(src.data_ptr(), out.data_ptr(), blocks, iters, stream), name)
     e1.record()
     torch.cuda.synchronize()
-    return blocks * 4.0 * iters * 4 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return blocks * 4.0 * iters * 4 * flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
 def plain_gemm_rate(device, constant, batch=16, reps=30):
@@ -413,7 +415,8 @@ def main():
             traffic=profiled_traffic("gemm_nn_fast_kernel", args.batch), traffic_source=traffic_file(args.batch),
             mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph "
                  "is the profiled command)",
-            mfma_bare_loop=round(mfma_bare_loop_rate(device), 1))
+            mfma_bare_loop=round(mfma_bare_loop_rate(device), 1),
+            bf16_mfma_bare_loop=round(mfma_bare_loop_rate(device, bf16=True), 1))
         extra["roofline_wgrad"] = rows["gemm_nt"]
         if prof_f32 is not None:
             rows32 = gemm_rows(prof_f32, 0)

@@ -97,10 +97,21 @@ int ctn_sizeof_dw_bwd_args(void);
  *   held in registers (read once from in[0..65535]); out receives blocks*256 floats.  FLOPs = blocks*4*iters*4*4096. */
 int ctn_probe_copy(const float* a, const float* b, float* y, int64_t n, void* stream);
 int ctn_probe_mfma_f32(const float* in, float* out, int blocks, int iters, void* stream);
+/* the same with v_mfma_f32_32x32x16_bf16 on bf16 bit patterns drawn from `in`: FLOPs = blocks*4*iters*4*32768 */
+int ctn_probe_mfma_bf16(const float* in, float* out, int blocks, int iters, void* stream);
 
 /* dst[k * ldd + coff + m] = src[m * K + k]  (m < M, k < K).  Lays a Conv1d(kernel_size=1) weight
  * (M_out, K_in) out k-major for ctn_gemm_nn. */
 int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64_t coff, void* stream);
+/* The same for any number of matrices in one launch per 64 of them (a training step lays out all its weights at once).
+ * `items` is host memory, read during the call. */
+typedef struct {
+    const float* src; float* dst;
+    int64_t ldd, coff;
+    int32_t M, K;
+} ctn_transpose_item;
+int ctn_transpose_batch(const ctn_transpose_item* items, int n_items, void* stream);
+int ctn_sizeof_transpose_item(void);
 
 /* Prepared weights.  In CTN_ARITH_BF16X3 the A operand of ctn_gemm_nn (a weight matrix, read by every block of the
  * launch) can be split into its three bf16 pieces ONCE per optimizer step instead of by every wave that reads it, and

@@ -69,6 +69,10 @@ class WPrepItem(C.Structure):
     ]
 
 
+class TransposeItem(C.Structure):
+    _fields_ = [("src", _p), ("dst", _p), ("ldd", _i64), ("coff", _i64), ("M", _i32), ("K", _i32)]
+
+
 class GemmNTArgs(C.Structure):
     _fields_ = [
         ("M", _i32), ("N", _i32), ("T", _i32), ("batch", _i32),
@@ -140,8 +144,11 @@ PROTOTYPES = {
     "ctn_sizeof_dw_bwd_args": (C.c_int, []),
     "ctn_probe_copy": (C.c_int, [_p, _p, _p, _i64, _p]),
     "ctn_probe_mfma_f32": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
+    "ctn_probe_mfma_bf16": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "ctn_transpose": (C.c_int, [_p, C.c_int, C.c_int, _p, _i64, _i64, _p]),
     "ctn_sizeof_wprep_item": (C.c_int, []),
+    "ctn_sizeof_transpose_item": (C.c_int, []),
+    "ctn_transpose_batch": (C.c_int, [C.POINTER(TransposeItem), C.c_int, _p]),
     "ctn_weight_prep_bytes": (_i64, [C.c_int, C.c_int]),
     "ctn_weight_prep": (C.c_int, [C.POINTER(WPrepItem), C.c_int, _p]),
     "ctn_segment": (C.c_int, [_p, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
@@ -193,6 +200,7 @@ _STRUCT_SIZES = {
     "ctn_sizeof_dw_fwd_args": DwFwdArgs,
     "ctn_sizeof_dw_bwd_args": DwBwdArgs,
     "ctn_sizeof_wprep_item": WPrepItem,
+    "ctn_sizeof_transpose_item": TransposeItem,
 }
 
 _lib = None

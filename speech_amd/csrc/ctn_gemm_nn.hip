@@ -778,8 +778,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
             wait_but_newest_x(kt + 2 < nk);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#ifndef CTN_DBG_PREP_NO_LOADS
             if (kt + 1 < nk) issue_ap(kt + 1, APb + ((kt + 1) & 1) * APSZ);
             if (kt + 3 < nk) issue_x(kt + 3, XLb + (kt % 3) * XLSZ);
+#endif
 #ifndef CTN_DBG_PREP_NO_CONVERT       // (timing builds: results are wrong)
             if (kt + 1 < nk) convert(XLb + ((kt + 1) % 3) * XLSZ, BPb + ((kt + 1) & 1) * BPSZ, (kt + 1) * FBK);
 #endif

@@ -56,6 +56,33 @@ __global__ __launch_bounds__(256) void probe_mfma_f32_kernel(const float* __rest
     out[tid] = s;
 }
 
+// The same with v_mfma_f32_32x32x16_bf16: operands are bf16 pieces of the random input (8 per lane and operand).
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void probe_mfma_bf16_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              const int iters) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    union { pbf16x8 v; unsigned u[4]; } a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[i].u[q] = __float_as_uint(in[(tid * 32 + i * 8 + q) & 65535]);          // two arbitrary bf16 bit patterns
+            b[i].u[q] = __float_as_uint(in[(tid * 32 + i * 8 + 4 + q) & 65535]) & 0x7f7f7f7fu;   // (finite)
+            a[i].u[q] &= 0x7f7f7f7fu;
+        }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[1].v, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[2].v, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3].v, b[3].v, c3, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    out[tid] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -79,6 +106,13 @@ int ctn_probe_mfma_f32(const float* in, float* out, int blocks, int iters, void*
     CTN_REQUIRE(in && out && blocks > 0 && iters > 0, "ctn_probe_mfma_f32: bad arguments");
     hipLaunchKernelGGL(probe_mfma_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, iters);
     CTN_CHECK_LAUNCH("ctn_probe_mfma_f32");
+    return CTN_OK;
+}
+
+int ctn_probe_mfma_bf16(const float* in, float* out, int blocks, int iters, void* stream) {
+    CTN_REQUIRE(in && out && blocks > 0 && iters > 0, "ctn_probe_mfma_bf16: bad arguments");
+    hipLaunchKernelGGL(probe_mfma_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, iters);
+    CTN_CHECK_LAUNCH("ctn_probe_mfma_bf16");
     return CTN_OK;
 }
 

@@ -31,6 +31,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+constexpr int TB_ITEMS = 64;
+struct transpose_batch {
+    ctn_transpose_item item[TB_ITEMS];
+    int32_t first_block[TB_ITEMS + 1];
+    int32_t n;
+};
+
+// One 32 x 32 tile per block; the block finds its matrix in the (by-value) table.
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const transpose_batch tb) {
+    __shared__ float tile[32][33];
+    int it = 0;
+    while (it + 1 < tb.n && (int)blockIdx.x >= tb.first_block[it + 1]) ++it;
+    const ctn_transpose_item& d = tb.item[it];
+    const int local = (int)blockIdx.x - tb.first_block[it];
+    const int tiles_k = (d.K + 31) >> 5;
+    const int m0 = (local / tiles_k) * 32, k0 = (local % tiles_k) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, k = k0 + tx;
+        tile[r][tx] = (m < d.M && k < d.K) ? d.src[(int64_t)m * d.K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, m = m0 + tx;
+        if (k < d.K && m < d.M) d.dst[(int64_t)k * d.ldd + d.coff + m] = tile[tx][r];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -43,6 +71,32 @@ int ctn_transpose(const float* src, int M, int K, float* dst, int64_t ldd, int64
     dim3 grid(ctn_cdiv(K, 32), ctn_cdiv(M, 32));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, M, K, dst, ldd, coff);
     CTN_CHECK_LAUNCH("ctn_transpose");
+    return CTN_OK;
+}
+
+int ctn_sizeof_transpose_item(void) { return (int)sizeof(ctn_transpose_item); }
+
+int ctn_transpose_batch(const ctn_transpose_item* items, int n_items, void* stream) {
+    CTN_REQUIRE(items && n_items > 0, "ctn_transpose_batch: no items");
+    for (int i = 0; i < n_items; ++i) {
+        const ctn_transpose_item& d = items[i];
+        CTN_REQUIRE(d.src && d.dst && d.M > 0 && d.K > 0 && d.coff >= 0 && d.ldd >= d.coff + d.M,
+                    "ctn_transpose_batch: item %d: bad arguments", i);
+    }
+    for (int base = 0; base < n_items; base += TB_ITEMS) {
+        transpose_batch tb;
+        tb.n = n_items - base < TB_ITEMS ? n_items - base : TB_ITEMS;
+        int64_t blocks = 0;
+        for (int i = 0; i < tb.n; ++i) {
+            tb.item[i] = items[base + i];
+            tb.first_block[i] = (int32_t)blocks;
+            blocks += (int64_t)ctn_cdiv(items[base + i].M, 32) * ctn_cdiv(items[base + i].K, 32);
+            CTN_REQUIRE(blocks < 0x7fffffff, "ctn_transpose_batch: too much work for one launch");
+        }
+        for (int i = tb.n; i <= TB_ITEMS; ++i) tb.first_block[i] = (int32_t)blocks;
+        hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb);
+        CTN_CHECK_LAUNCH("ctn_transpose_batch");
+    }
     return CTN_OK;
 }
 

@@ -139,34 +139,62 @@ def _layer_parts(L):
 
 
 class PreparedWeights:
-    """Every weight operand of the separator's pointwise GEMMs in prepared form, in one bf16 buffer; refresh() splits
-    the current parameter values into it with ctn_weight_prep (a few launches) -- once per optimizer step, on the
-    stream the pass starts from.  The parameters must keep their addresses (views of a flat buffer)."""
+    """The weight operands of the separator's pointwise GEMMs, laid out once per optimizer step instead of once per use:
+    k-major fp32 copies of every weight the forward GEMMs read (ctn_transpose_batch: two launches instead of 73) and,
+    when `planes` is asked for, every weight operand in prepared form (ctn_weight_prep) in one bf16 buffer.  refresh()
+    runs on the stream the pass starts from.  The parameters must keep their addresses (views of a flat buffer)."""
 
-    def __init__(self, mp):
+    def __init__(self, mp, planes=False):
+        dev = mp.Wb.device
         self.layers = [dict() for _ in mp.layers]
         self.sep = {}
-        specs = []
-        for i, (L, _) in enumerate(mp.layers):
-            for key, (K, M, K1, parts) in _layer_parts(L).items():
-                specs.append((self.layers[i], key, K, M, K1, parts))
-        for key, (K, M, K1, parts) in _separator_parts(mp).items():
-            specs.append((self.sep, key, K, M, K1, parts))
-        specs = [sp for sp in specs if sp[3] > 64 and sp[3] % 4 == 0 and sp[2] % 16 == 0 and (sp[4] or 0) % 16 == 0]
-        total = sum(ops.weight_planes_numel(K, M) for _, _, K, M, _, _ in specs)
-        dev = mp.Wb.device
-        self.buf = torch.zeros(max(total, 8), device=dev, dtype=torch.bfloat16)
-        entries, off = [], 0
-        for store, key, K, M, K1, parts in specs:
-            n = ops.weight_planes_numel(K, M)
-            dst = self.buf[off:off + n]
-            off += n
+        # ---- k-major fp32: W1t (Bc, H) and the two heads side by side (H, Mo + Sc) per layer; Wbt, Wmt
+        entries, self._keep = [], []
+
+        def kmajor(store, key, K, M, pieces):          # pieces: [(source (m, K), column offset)]
+            dst = torch.empty((K, M), device=dev, dtype=torch.float32)
             store[key] = dst
-            entries += [(src, tr, ko, mo, K, M, dst) for src, tr, ko, mo in parts]
-        self._sources = [e[0] for e in entries]                   # keep the views (and their storage) alive
-        self.items = ops.wprep_items(entries) if entries else None
+            for src, coff in pieces:
+                src = src.contiguous()
+                self._keep.append(src)
+                entries.append((src, dst, M, coff))
+
+        for i, (L, _) in enumerate(mp.layers):
+            H, Bc, Sc = L.H, L.Bc, L.Sc
+            Mo = Bc if L.dual else 0
+            kmajor(self.layers[i], "W1t", Bc, H, [(L.W1.view(H, Bc), 0)])
+            kmajor(self.layers[i], "Wct", H, Mo + Sc,
+                   ([(L.Wo.view(Bc, H), 0)] if L.dual else []) + [(L.Ws.view(Sc, H), Mo)])
+        Bc, N = mp.Wb.shape[0], mp.Wb.shape[1]
+        Mm, Sc = mp.Wm.shape[0], mp.Wm.shape[1]
+        kmajor(self.sep, "Wbt", N, Bc, [(mp.Wb.detach().view(Bc, N), 0)])
+        kmajor(self.sep, "Wmt", Sc, Mm, [(mp.Wm.detach().view(Mm, Sc), 0)])
+        self.t_items = ops.transpose_items(entries)
+        # ---- prepared planes
+        self.items = None
+        if planes:
+            specs = []
+            for i, (L, _) in enumerate(mp.layers):
+                for key, (K, M, K1, parts) in _layer_parts(L).items():
+                    specs.append((self.layers[i], key, K, M, K1, parts))
+            for key, (K, M, K1, parts) in _separator_parts(mp).items():
+                specs.append((self.sep, key, K, M, K1, parts))
+            specs = [sp for sp in specs if sp[3] > 64 and sp[3] % 4 == 0 and sp[2] % 16 == 0 and sp[2] <= 4096 and
+                     (sp[4] or 0) % 16 == 0]
+            total = sum(ops.weight_planes_numel(K, M) for _, _, K, M, _, _ in specs)
+            self.buf = torch.zeros(max(total, 8), device=dev, dtype=torch.bfloat16)
+            pentries, off = [], 0
+            for store, key, K, M, K1, parts in specs:
+                n = ops.weight_planes_numel(K, M)
+                dst = self.buf[off:off + n]
+                off += n
+                store[key] = dst
+                pentries += [(src, tr, ko, mo, K, M, dst) for src, tr, ko, mo in parts]
+            self._keep += [e[0] for e in pentries]
+            self.items = ops.wprep_items(pentries) if pentries else None
 
     def refresh(self):
+        ops.transpose_batch(self.t_items)
         if self.items is not None:
             ops.weight_prep(self.items)
 
@@ -208,8 +236,10 @@ def layer_forward(L, x, skip, accumulate, dilation, causal, eps):
     W1p = _prepared(L.planes, "W1f", *parts["W1f"][:2], parts["W1f"][3], dev)
     W1t = None
     if W1p is None:
-        W1t = torch.empty((Bc, H), device=dev, dtype=torch.float32)
-        ops.transpose(L.W1.view(H, Bc), W1t, H)
+        W1t = L.planes.get("W1t") if L.planes is not None else None
+        if W1t is None:
+            W1t = torch.empty((Bc, H), device=dev, dtype=torch.float32)
+            ops.transpose(L.W1.view(H, Bc), W1t, H)
     y1 = new_act(B, H, T, dev)
     acc1 = Accum(B, T, causal, dev)
     st1, fin1 = ops.stats_request(acc1, B, H, T, eps, dev)
@@ -219,7 +249,7 @@ def layer_forward(L, x, skip, accumulate, dilation, causal, eps):
     # depthwise
     y2 = new_act(B, H, T, dev)
     acc2 = Accum(B, T, causal, dev)
-    st2, fin2 = ops.stats_request(acc2, B, H, T, eps, dev)
+    st2, fin2 = ops.stats_request(acc2, B, H, T, eps, dev, producer="dw")
     ops.dw_fwd(y1, L.wd.view(H, P), L.bd, y2, dilation, _pads(P, dilation, causal), xflags=XF_PRELU | XF_NORM,
                alpha_in=L.a1, stat=st1, gamma=L.g1.view(-1), beta=L.be1.view(-1), alpha_out=L.a2, acc=acc2, fin=fin2)
     if st2 is None:
@@ -230,10 +260,12 @@ def layer_forward(L, x, skip, accumulate, dilation, causal, eps):
     Wcp = _prepared(L.planes, "Hf", *parts["Hf"][:2], parts["Hf"][3], dev)
     Wct = None
     if Wcp is None:
-        Wct = torch.empty((H, Mt), device=dev, dtype=torch.float32)
-        if L.dual:
-            ops.transpose(L.Wo.view(Bc, H), Wct, Mt, 0)
-        ops.transpose(L.Ws.view(Sc, H), Wct, Mt, Mo)
+        Wct = L.planes.get("Wct") if L.planes is not None else None
+        if Wct is None:
+            Wct = torch.empty((H, Mt), device=dev, dtype=torch.float32)
+            if L.dual:
+                ops.transpose(L.Wo.view(Bc, H), Wct, Mt, 0)
+            ops.transpose(L.Ws.view(Sc, H), Wct, Mt, Mo)
     out = new_act(B, Bc, T, dev) if L.dual else None
     ops.gemm_nn(Mt, T, H, B, Wct, Mt, y2, out if L.dual else skip, xflags=XF_PRELU | XF_NORM, alpha=L.a2, stat=st2,
                 gamma=L.g2.view(-1), beta=L.be2.view(-1), bias=L.bo, bias2=L.bs, emode=EPI_HEADS, Mo=Mo,
@@ -274,7 +306,7 @@ def layer_backward(L, saved, dout, dskip, sink, dilation, causal, eps):
     # depthwise backward (+ norm-2 / PReLU-2 backward on load, norm-1 sums on the way out)
     dn1 = new_act(B, H, T, dev)
     bacc1 = Accum(B, T, causal, dev)
-    finb1 = ops.coefs_request(bacc1, st1, B, H, T)
+    finb1 = ops.coefs_request(bacc1, st1, B, H, T, producer="dw")
     ops.dw_bwd(dn2, y1, L.wd.view(H, P), sink.g(o["wd"]).view(H, P), sink.g(o["bd"]), dn1, dilation,
                _pads(P, dilation, causal), xflags=XF_PRELU | XF_NORM, alpha1=L.a1, stat1=st1, gamma1=L.g1.view(-1),
                beta1=L.be1.view(-1), dgamma1=sink.g(o["g1"]).view(-1), dbeta1=sink.g(o["be1"]).view(-1), iacc=bacc1,
@@ -649,8 +681,10 @@ def separator_forward(mp, w, st0_acc, eps, sigmoid=True):
     Wbp = _prepared(mp.planes, "Wbf", *sparts["Wbf"][:2], sparts["Wbf"][3], dev)
     Wbt = None
     if Wbp is None:
-        Wbt = torch.empty((N, Bc), device=dev, dtype=torch.float32)
-        ops.transpose(mp.Wb.detach().view(Bc, N), Wbt, Bc)
+        Wbt = mp.planes.get("Wbt") if mp.planes is not None else None
+        if Wbt is None:
+            Wbt = torch.empty((N, Bc), device=dev, dtype=torch.float32)
+            ops.transpose(mp.Wb.detach().view(Bc, N), Wbt, Bc)
     x = new_act(B, Bc, T, dev)
     ops.gemm_nn(Bc, T, N, B, Wbt, Bc, w, x, xflags=XF_NORM, stat=st0, gamma=mp.g0.detach().view(-1),
                 beta=mp.be0.detach().view(-1), bias=mp.bb.detach(), A_prep=Wbp)
@@ -665,8 +699,10 @@ def separator_forward(mp, w, st0_acc, eps, sigmoid=True):
     Wmp = _prepared(mp.planes, "Wmf", *sparts["Wmf"][:2], sparts["Wmf"][3], dev)
     Wmt = None
     if Wmp is None:
-        Wmt = torch.empty((Sc, M), device=dev, dtype=torch.float32)
-        ops.transpose(mp.Wm.detach().view(M, Sc), Wmt, M)
+        Wmt = mp.planes.get("Wmt") if mp.planes is not None else None
+        if Wmt is None:
+            Wmt = torch.empty((Sc, M), device=dev, dtype=torch.float32)
+            ops.transpose(mp.Wm.detach().view(M, Sc), Wmt, M)
     mask = new_act(B, M, T, dev)
     ops.gemm_nn(M, T, Sc, B, Wmt, M, skip, mask, xflags=XF_PRELU, alpha=mp.a_sep.detach(), bias=mp.bm.detach(),
                 emode=EPI_SIGMOID if sigmoid else EPI_STORE, A_prep=Wmp)

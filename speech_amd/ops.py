@@ -150,29 +150,35 @@ class Accum:
 
 
 # A producer of gLN sums can finish the reduction itself (ctn_finish in include/ctn.h): the block that adds the last
-# partial sums writes mean / rstd (or the backward coefficients), and the stand-alone finalize launch disappears (98
-# launches of a training pass).  Off by default: a block must see its additions performed before it takes its ticket, and
-# that wait also covers the block's output stores, which it otherwise leaves in flight when it retires -- the depthwise
-# kernels run at less than half their rate that way (85 -> 202 us per launch at batch 32).  CTN_FOLD_FINISH=1 switches
-# it on (it pays where a pass is bound by its launch count).
-FOLD_FINISH = os.environ.get("CTN_FOLD_FINISH", "0") != "0"
+# partial sums writes mean / rstd (or the backward coefficients), and the stand-alone finalize launch disappears.
+# Measured, it does not pay at either end: a block must see its additions performed before it takes its ticket, and that
+# wait also covers the block's output stores, which it otherwise leaves in flight when it retires.  The depthwise
+# kernels, whose blocks stream one row and retire, run at less than half their rate that way (85 -> 202 us per launch at
+# batch 32); the GEMM epilogues lose 2 %, which at batch 32 cancels the 49 launches saved and at batch 2 costs 3 % of the
+# step.  Hence off by default; CTN_FOLD_FINISH = all | gemm | 0 chooses the producers that fold.
+def _initial_fold():
+    v = os.environ.get("CTN_FOLD_FINISH", "0").strip().lower()
+    return {"all": ("gemm", "dw"), "1": ("gemm", "dw"), "gemm": ("gemm",), "0": (), "none": ()}.get(v, ())
 
 
-def stats_request(acc, B, Cc, T, eps, device):
-    """(stat, fin) for a producer about to fill `acc` with forward statistics: fin goes to the producer's `fin=`
-    argument and stat is complete when the producer has run; (None, None) when the reduction cannot be finished in
-    the producer (cLN, or switched off) -- call finalize_stats() behind the producer then."""
-    if not FOLD_FINISH or acc.sums is None:
+FOLD_FINISH = _initial_fold()         # producers that finish their reductions: any of "gemm", "dw"
+
+
+def stats_request(acc, B, Cc, T, eps, device, producer="gemm"):
+    """(stat, fin) for a producer ("gemm" or "dw") about to fill `acc` with forward statistics: fin goes to the
+    producer's `fin=` argument and stat is complete when the producer has run; (None, None) when the reduction is not
+    finished in the producer (cLN, or not switched on for this kind of producer) -- call finalize_stats() behind it then."""
+    if producer not in FOLD_FINISH or acc.sums is None:
         return None, None
     stat = Stat(torch.empty((B,), device=device, dtype=torch.float32),
                 torch.empty((B,), device=device, dtype=torch.float32), 1, 0, False)
     return stat, (_lib.FIN_STATS, acc, stat.mean, stat.rstd, None, float(Cc) * float(T), eps)
 
 
-def coefs_request(acc, stat, B, Cc, T):
+def coefs_request(acc, stat, B, Cc, T, producer="gemm"):
     """fin for a producer about to fill `acc` with the backward sums of `stat`'s norm: stat.c1 / stat.c2 are complete
-    when the producer has run.  None when not possible: call bwd_coefs() behind the producer then."""
-    if not FOLD_FINISH or acc.sums is None or stat.cln:
+    when the producer has run.  None when the producer does not finish them: call bwd_coefs() behind it then."""
+    if producer not in FOLD_FINISH or acc.sums is None or stat.cln:
         return None
     stat.c1 = torch.empty_like(stat.mean)
     stat.c2 = torch.empty_like(stat.mean)
@@ -290,6 +296,23 @@ def transpose(src2d, dst, ldd, coff=0):
     lib = _lib.load()
     M, K = src2d.shape
     _lib.check(lib.ctn_transpose(_ptr(src2d), M, K, _ptr(dst), ldd, coff, _stream()), "ctn_transpose")
+
+
+def transpose_items(entries):
+    """ctypes array of ctn_transpose_item from (src2d (M, K) contiguous fp32, dst, ldd, coff) tuples; the caller keeps the
+    tensors alive."""
+    arr = (_lib.TransposeItem * len(entries))()
+    for it, (src, dst, ldd, coff) in zip(arr, entries):
+        _require_cuda(src, dst)
+        assert src.dim() == 2 and src.is_contiguous() and src.dtype == torch.float32 and dst.dtype == torch.float32
+        assert dst.is_contiguous() and dst.numel() >= (src.shape[1] - 1) * ldd + coff + src.shape[0]
+        it.src, it.dst, it.ldd, it.coff, it.M, it.K = _ptr(src), _ptr(dst), ldd, coff, src.shape[0], src.shape[1]
+    return arr
+
+
+def transpose_batch(items):
+    lib = _lib.load()
+    _lib.check(lib.ctn_transpose_batch(items, len(items), _stream()), "ctn_transpose_batch")
 
 
 def prep_usable(M, K, K1=None):

@@ -98,8 +98,9 @@ class FlatTrainer:
         self.v = torch.zeros_like(self.flat_p)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.step_count = 0
-        # weight operands of the pointwise GEMMs in prepared form (default arithmetic): one buffer, refreshed per pass
-        self._prepared = PreparedWeights(ModelParams(self.params, model.fused_config()))
+        # weight operands of the pointwise GEMMs laid out once per pass (k-major copies; prepared planes on request)
+        self._prepared = PreparedWeights(ModelParams(self.params, model.fused_config()),
+                                         planes=functional.USE_PREPARED_WEIGHTS)
         if self.world > 1:                         # identical replicas: broadcast rank 0's weights
             dist.broadcast(self.flat_p, src=0, group=self.group)
 
@@ -209,10 +210,10 @@ class FlatTrainer:
         regions = self._region_table() if overlap else []
         hook_layers = {first: k for k, (first, _, _, _) in enumerate(regions) if first is not None}
         self._exchanged = False
-        planes = None
-        if functional.USE_PREPARED_WEIGHTS and ops.get_gemm_split() == 3:
-            self._prepared.refresh()               # on the stream every sub-batch stream waits for below
-            planes = self._prepared
+        if self._prepared.items is None and functional.USE_PREPARED_WEIGHTS:     # switched on after construction
+            self._prepared = PreparedWeights(ModelParams(self.params, self.model.fused_config()), planes=True)
+        self._prepared.refresh()                   # on the stream every sub-batch stream waits for below
+        planes = self._prepared
         if n == 1:
             main = torch.cuda.current_stream()
             cfg = self.model.fused_config()

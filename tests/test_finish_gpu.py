@@ -17,7 +17,7 @@ def dev():
 def fold_on():
     from speech_amd import ops
     before = ops.FOLD_FINISH
-    ops.FOLD_FINISH = True
+    ops.FOLD_FINISH = ("gemm", "dw")
     yield
     ops.FOLD_FINISH = before
 
@@ -87,7 +87,7 @@ def test_depthwise_kernels_finish_their_reductions(C, T, B, d):
     st1 = ops.finalize_stats(acc0, B, C, T, 1e-8, dev())
     y = ops.new_act(B, C, T, dev())
     acc = ops.Accum(B, T, False, dev())
-    st2, fin = ops.stats_request(acc, B, C, T, 1e-8, dev())
+    st2, fin = ops.stats_request(acc, B, C, T, 1e-8, dev(), producer="dw")
     ops.dw_fwd(x, w, bias, y, d, d, xflags=ops.XF_PRELU | ops.XF_NORM, alpha_in=a1, stat=st1, gamma=g1, beta=be1,
                alpha_out=a2, acc=acc, fin=fin)
     _same_as_standalone(acc, st2, B, C, T, 1e-8, False)
@@ -100,7 +100,7 @@ def test_depthwise_kernels_finish_their_reductions(C, T, B, d):
         dg1, db1, dg2, db2 = (torch.zeros(C, device=dev()) for _ in range(4))
         da2 = torch.zeros(ops._lib.STAT_SLOTS, device=dev(), dtype=torch.float64)
         bacc = ops.Accum(B, T, False, dev())
-        finb = ops.coefs_request(bacc, st1, B, C, T)
+        finb = ops.coefs_request(bacc, st1, B, C, T, producer="dw")
         ops.dw_bwd(dn2, x, w, dw, db, dn1, d, d, xflags=ops.XF_PRELU | ops.XF_NORM, alpha1=a1, stat1=st1, gamma1=g1,
                    beta1=be1, dgamma1=dg1, dbeta1=db1, iacc=bacc, y2=y, alpha2=a2, stat2=st2, gamma2=g2, dgamma2=dg2,
                    dbeta2=db2, dalpha2=da2, bias=bias, recompute_y2=recompute, fin=finb)
@@ -121,7 +121,7 @@ def test_whole_network_gradients_do_not_depend_on_where_the_reductions_finish():
     mix, src = synth.make_batch(3, 2, 8000, 5)
     mix, src = mix.to(dev()), src.to(dev())
     outs = []
-    for fold in (True, False):
+    for fold in (("gemm", "dw"), ()):
         ops.FOLD_FINISH = fold
         try:
             tr = FlatTrainer(build_model(cfg, dev()), PIT1d(NegSISDR(), 2))
@@ -129,6 +129,6 @@ def test_whole_network_gradients_do_not_depend_on_where_the_reductions_finish():
             torch.cuda.synchronize()
             outs.append((loss.item(), tr.flat_g.clone()))
         finally:
-            ops.FOLD_FINISH = True            # (the fixture restores the module's own default)
+            ops.FOLD_FINISH = ("gemm", "dw")  # (the fixture restores the module's own default)
     assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * max(1.0, abs(outs[1][0]))
     assert_close(outs[0][1], outs[1][1], 2e-5, "flat gradient")

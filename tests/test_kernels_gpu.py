@@ -80,6 +80,25 @@ def test_transpose():
     assert dst.cpu()[:, :20].abs().sum() == 0
 
 
+def test_transpose_batch():
+    """Many matrices in one call (more than one launch's worth of table entries), two of them into one destination."""
+    from speech_amd import ops
+    shapes = [(70, 45), (128, 512), (512, 128), (33, 1), (1, 40)] * 14          # 70 items
+    srcs = [rnd(sh, 100 + i).float().to(dev()) for i, sh in enumerate(shapes)]
+    dsts = [torch.zeros(K, M + 7, device=dev()) for (M, K) in shapes]
+    entries = [(s_, d_, d_.shape[1], 3) for s_, d_ in zip(srcs, dsts)]
+    a, b = rnd((20, 64), 300).float().to(dev()), rnd((44, 64), 301).float().to(dev())
+    both = torch.zeros(64, 64, device=dev())
+    entries += [(a, both, 64, 0), (b, both, 64, 20)]
+    ops.transpose_batch(ops.transpose_items(entries))
+    torch.cuda.synchronize()
+    for s_, d_ in zip(srcs, dsts):
+        M = s_.shape[0]
+        assert torch.equal(d_[:, 3:3 + M], s_.t())
+        assert d_[:, :3].abs().sum() == 0 and d_[:, 3 + M:].abs().sum() == 0
+    assert torch.equal(both, torch.cat([a, b], 0).t())
+
+
 @pytest.mark.parametrize("M,K,T,batch", [(40, 24, 301, 2), (128, 128, 515, 2), (200, 130, 257, 1), (512, 128, 3999, 1),
                                          (32, 512, 100, 3), (64, 64, 64, 1)])
 @pytest.mark.parametrize("width", [64, 128])

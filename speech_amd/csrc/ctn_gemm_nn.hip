@@ -400,6 +400,11 @@ __global__ __launch_bounds__(NTH) void gemm_nn_kernel(const ctn_gemm_nn_args a, 
 // several generations of blocks per launch, which takes co-resident blocks out of lockstep.
 // ================================================================================================
 constexpr int FBM = 128, FBK = 16;
+#ifndef CTN_NN_W3
+#define CTN_NN_W3 4      // waves per SIMD asked of the compiler for the three-piece variant without operand transform: it takes
+                       // 131 registers unasked, three more than four waves allow; 20 bytes of spill buy the fourth wave
+                       // (-6 % per launch).  The variants with a transform lose with the same request (+6 %).
+#endif
 
 #ifdef CTN_DBG_STAMPS
 // Diagnostic build only: wave 0 of every block records shader-clock stamps of its phases.
@@ -477,7 +482,7 @@ __device__ __forceinline__ void ctn_lds_store8_untracked(void* p, u32x2 v) {
 // LDS reads per fragment set and the matrix instructions; products and their order are those of SPLIT = 3, so the
 // results are bit-identical.
 template <int FBN_, int XF, bool BWD, int SPLIT = 0>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : 2), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : (SPLIT == 3 && XF == 0 && !BWD ? CTN_NN_W3 : 2)), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
     // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -469,9 +469,11 @@ def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, 
 
 
 def pick_kchunk(T, batch, tiles, target_blocks=1024):
-    """Time steps per wgrad block: one generation of 4 blocks on each of the 256 CUs (every block ends with
-    atomic adds of its whole output tile, the cost that grows with the number of chunks), chunks >= 256 frames."""
-    chunks = max(1, target_blocks // max(1, batch * tiles))
+    """Time steps per wgrad block: about one generation of resident blocks on the 256 CUs (every block ends with atomic
+    adds of its whole output tile, the cost that grows with the number of chunks), chunks >= 256 frames.  The number of
+    chunks is ROUNDED to the nearest: 512 blocks per chunk against 768 slots run faster as 1024 blocks (a third of a
+    generation of tail) than as 512 (a third of the chip's slots empty throughout): 288 -> 265 us on the heads' launch."""
+    chunks = max(1, int(target_blocks / max(1, batch * tiles) + 0.5))
     k = (T + chunks - 1) // chunks
     k = max(256, (k + 31) // 32 * 32)
     return k

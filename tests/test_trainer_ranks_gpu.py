@@ -52,6 +52,38 @@ def _train(variant, world, rank, device):
     return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, losses
 
 
+def _epoch_losses(world, rank, device, out_dir):
+    """One epoch of the epoch-loop trainer (speech_amd.driver.AdhocTrainer): training loss and validation loss.  The
+    validation set has 5 utterances; with two ranks, rank 0 sees 3 of them and rank 1 sees 2 (uneven shards, ragged last
+    batch), and the loss both ranks report must be the mean over all 5."""
+    import types
+    import cases
+    import convtasnet_oracle as O
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    from speech_amd.driver import AdhocTrainer
+    from speech_amd.trainer import shard_batch
+    from test_parity_gpu import build, load_state
+    cfg = dict(O.CONFIG_SMALL, sep_num_blocks=1, sep_num_layers=2)
+    model = load_state(build(cfg), cases.e2e_state(cfg)).to(device)
+    train = []
+    for i in range(2):
+        mixture, sources = cases.e2e_batch(cfg, 4, 4000, 70 + i)
+        if world > 1:
+            mixture, sources = shard_batch(mixture, sources, rank, world)
+        train.append((mixture, sources))
+    vm, vs = cases.e2e_batch(cfg, 5, 4000, 90)
+    mine = list(range(5)) if world == 1 else ([0, 1, 2] if rank == 0 else [3, 4])
+    valid = [(vm[mine[j:j + 2]], vs[mine[j:j + 2]]) for j in range(0, len(mine), 2)]     # batches of two, the last ragged
+    tag = "w{}r{}".format(world, rank)
+    args = types.SimpleNamespace(sample_rate=8000, n_sources=2, max_norm=5.0, epochs=1, use_cuda=True, continue_from=None,
+                                 overwrite=True, model_dir=os.path.join(out_dir, tag, "model"),
+                                 loss_dir=os.path.join(out_dir, tag, "loss"), sample_dir=os.path.join(out_dir, tag, "sample"))
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    tr = AdhocTrainer(model, {"train": train, "valid": valid}, PIT1d(NegSISDR(), 2), optimizer, args)
+    return [float(v) for v in tr.run_one_epoch(0)]
+
+
 def _worker(rank, world, port, out_dir):
     _paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -64,6 +96,8 @@ def _worker(rank, world, port, out_dir):
         params, losses = _train(variant, world, rank, device)
         out[variant[0]] = dict(params=params, losses=losses)
         dist.barrier()
+    out["epoch"] = _epoch_losses(world, rank, device, out_dir)
+    dist.barrier()
     torch.save(out, os.path.join(out_dir, "rank{}.pt".format(rank)))
     dist.destroy_process_group()
 
@@ -74,6 +108,11 @@ def test_two_ranks_every_exchange_schedule_equals_global_batch(tmp_path):
     mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     ranks = [torch.load(os.path.join(str(tmp_path), "rank{}.pt".format(r)), weights_only=True) for r in range(world)]
     single, single_losses = _train(("single", 1, False, False, 1), 1, 0, torch.device("cuda", 0))
+    # the epoch loop: both ranks report the same losses, equal to one process on the whole training and validation sets
+    single_epoch = _epoch_losses(1, 0, torch.device("cuda", 0), str(tmp_path))
+    assert ranks[0]["epoch"] == ranks[1]["epoch"]
+    for a, b in zip(ranks[0]["epoch"], single_epoch):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (ranks[0]["epoch"], single_epoch)
     for name, *_ in VARIANTS:
         p0, p1 = ranks[0][name]["params"], ranks[1][name]["params"]
         mean_loss = [(a + b) / 2 for a, b in zip(ranks[0][name]["losses"], ranks[1][name]["losses"])]

@@ -392,6 +392,39 @@ class LayerNormFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ recurrence
+def reduce_matmul(a, b):
+    """a (R, M), b (R, N), rows uniformly strided -> a^T b (M, N) for R in the hundreds of thousands (every (sequence,
+    step) pair of a recurrent layer).  As one product the GEMM library runs it on M*N / tile workgroups -- 16 for a
+    512 x 128 weight gradient, on 256 CUs -- so the reduction is cut into batched partial products that are added."""
+    R = a.shape[0]
+    C = max(1, min(256, R // 1024))
+    per = R // C
+    main = per * C
+    out = torch.bmm(a[:main].view(C, per, a.shape[1]).transpose(1, 2), b[:main].view(C, per, b.shape[1])).sum(dim=0)
+    if main < R:
+        out = out + a[main:].t() @ b[main:]
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear over (rows, features) with the weight gradient as a split reduction (reduce_matmul)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shape = x.shape
+        x2 = x.detach().reshape(-1, shape[-1])
+        ctx.saved = (x2, weight, bias is not None, shape)
+        y = torch.addmm(bias.detach(), x2, weight.detach().t()) if bias is not None else x2 @ weight.detach().t()
+        return y.view(shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, has_bias, shape = ctx.saved
+        dy2 = dy.reshape(-1, weight.shape[0])
+        dx = (dy2 @ weight.detach()).view(shape) if ctx.needs_input_grad[0] else None
+        return dx, reduce_matmul(dy2, x2), dy2.sum(dim=0) if has_bias else None
+
+
 class LstmFn(torch.autograd.Function):
     """nn.LSTM(batch_first=True, num_layers=1), one or two directions, zero initial state, on the persistent recurrence
     kernels: x (N, T, F) -> (N, T, D*H).  The input projection of all steps is one GEMM in front of the recurrence
@@ -421,18 +454,26 @@ class LstmFn(torch.autograd.Function):
         dgates = ops.lstm_bwd(dout.contiguous().float().view(N, T, n_dir, H), save, whh)      # (N, T, D, 4H)
         dg2 = dgates.view(N * T, n_dir * 4 * H)
         dx = (dg2 @ w_ih_all).view(N, T, F_in) if ctx.needs_input_grad[0] else None
-        dw_ih_all = dg2.t() @ x2                                          # (D*4H, F)
+        dw_ih_all = reduce_matmul(dg2, x2)                                # (D*4H, F)
         db_all = dg2.sum(dim=0)
+        # recurrent weights: sum over (n, t) of dgates[n, t]^T h[n, t -+ 1], h of the step before t in the direction's own
+        # order.  Over the flat (n, t) index that is one shifted product of the whole tensors, minus the N - 1 terms that
+        # pair the first step of a sequence with the last state of its neighbour (no shifted copy of h is made).
+        dg3 = dgates.view(N * T, n_dir, 4 * H)
+        h3 = hout.view(N * T, n_dir, H)
         grads = []
         for d in range(n_dir):
-            # h of the step before t in the direction's own order: shift by one step, zeros at its first step
-            hprev = torch.zeros((N, T, H), device=hout.device, dtype=torch.float32)
-            if T > 1:
-                if d == 0:
-                    hprev[:, 1:] = hout[:, :-1, d]
-                else:
-                    hprev[:, :-1] = hout[:, 1:, d]
-            dw_hh = dgates[:, :, d].reshape(N * T, 4 * H).t() @ hprev.view(N * T, H)
+            dg, h = dg3[:, d], h3[:, d]                                   # (N*T, 4H), (N*T, H): strided views
+            if N * T < 2:
+                dw_hh = torch.zeros((4 * H, H), device=hout.device, dtype=torch.float32)
+            elif d == 0:
+                dw_hh = reduce_matmul(dg[1:], h[:-1])
+                if N > 1:
+                    dw_hh = dw_hh - dgates[1:, 0, d].t() @ hout[:-1, T - 1, d]
+            else:
+                dw_hh = reduce_matmul(dg[:-1], h[1:])
+                if N > 1:
+                    dw_hh = dw_hh - dgates[:-1, T - 1, d].t() @ hout[1:, 0, d]
             db = db_all[d * 4 * H:(d + 1) * 4 * H]
             grads += [dw_ih_all[d * 4 * H:(d + 1) * 4 * H], dw_hh, db, db]
         return (dx, None) + tuple(grads)

@@ -14,7 +14,7 @@ kernels as well; the linear layer is torch's (a plain library GEMM), the axis sh
 import torch.nn as nn
 
 from .. import ops
-from ..functional import LstmFn
+from ..functional import LinearFn, LstmFn
 from ..utils.tasnet import choose_layer_norm
 
 EPS = 1e-12
@@ -69,7 +69,7 @@ class _PathRNN(nn.Module):
         outer, steps = (K, S) if self.walk_chunks else (S, K)
         sequences = input.permute(*order).reshape(batch_size * outer, steps, num_features)
         y, _ = self.rnn(sequences)
-        y = self.fc(y)                                                     # (sequences, steps, features)
+        y = LinearFn.apply(y, self.fc.weight, self.fc.bias)                # (sequences, steps, features)
         y = y.view(batch_size, outer * steps, num_features).permute(0, 2, 1).contiguous()
         if self.norm:
             y = self.norm1d(y)                                             # over (features, outer * steps)

@@ -1,6 +1,6 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE counter_collection CSVs).
 FETCH_SIZE (KB) is doubled: on gfx950 it tallies the 128-byte requests of wide streaming reads at 64 bytes.
-usage: summarize_pmc.py fetch.csv write.csv [out.json]"""
+usage: summarize_pmc.py fetch.csv write.csv [out.json [batch_per_gpu]]"""
 import collections, csv, json, re, sys
 
 
@@ -28,4 +28,14 @@ for k, d in list(out.items())[:16]:
     print("%-46s launches %4d  read %8.1f MB  write %8.1f MB per launch" %
           (k[:46], d["launches"], d["read_bytes_per_launch"] / 1e6, d["write_bytes_per_launch"] / 1e6))
 if len(sys.argv) > 3:
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    doc = {
+        "batch_per_gpu": int(sys.argv[4]) if len(sys.argv) > 4 else 32,
+        "command": "bench.py --steps 1 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --no-split-probe --no-recipe-batch "
+                   "--no-roofline (default arithmetic: three bf16 pieces)",
+        "collection": "two rocprofv3 --pmc passes of the same command (FETCH_SIZE, WRITE_SIZE), tools/profile_bench.sh; "
+                      "FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16-byte-per-lane streaming reads at 64 "
+                      "bytes); kernels that read 4 bytes per lane (maskdecode_*, encoder_bwd) are over-counted by that "
+                      "correction",
+        "kernels": out,
+    }
+    json.dump(doc, open(sys.argv[3], "w"), indent=1)

@@ -21,6 +21,8 @@
 //
 // Hidden sizes up to 128 (multiple of 4) are padded to HP = 64 or 128 with zero weights: padded units stay at
 // c = h = 0 and are never stored.
+#include <stdlib.h>
+
 #include "ctn_common.h"
 
 namespace {
@@ -155,6 +157,246 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------ forward, bf16 matrix unit
+// The same walk with the recurrent product on v_mfma_f32_16x16x32_bf16 in the exact three-piece arithmetic of the
+// pointwise GEMMs (CTN_ARITH_BF16X3): W_hh and h are split as x = hi + mid + lo, each piece the next eight significant
+// bits of the fp32 value, and the six piece products above 2^-22 of the largest are accumulated in fp32 on top of xproj_t.
+// A step's matrix work drops from 256 instructions of 32 cycles to 192 of 16.  W_hh's hi and mid pieces stay in
+// registers as A fragments (256 registers per lane, as the fp32 weights did); the lo pieces, used by one product in six,
+// live in LDS (128 KB at hidden size 128) and are read per step; h_t is split by the wave that computes it and written to
+// LDS as B fragments (three 16-byte reads per 32 units and wave in the next step instead of 32 four-byte reads).
+typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
+
+// Two floats -> the packed pieces of both: hi, mid, lo (low half-word = first value)
+__device__ __forceinline__ void lstm_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned ru0 = __float_as_uint(r0), ru1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(ru1, ru0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(ru0 & 0xffff0000u), q1 = r1 - __uint_as_float(ru1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+union lstm_frag {
+    lbf16x8 v;
+    unsigned u[4];
+};
+
+// FULL: H fills the padded tile (H == 64 NT); the stores then need no condition: a padded sequence repeats the block's last
+// real one, input and all, and writes the same values to the same places.  Without a branch around the stores the
+// compiler counts them exactly when it waits for the prefetched input of the next step, so that wait does not include them.
+template <int NT, bool FULL>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_b3_kernel(
+    const float* __restrict__ xproj, const float* __restrict__ whh, float* __restrict__ hout, float* __restrict__ save,
+    const int N, const int T, const int H, const int D) {
+    constexpr int HP = 64 * NT, KS = HP / 32, UPW = 16 * NT;          // padded units, 32-unit k-steps, units per wave
+    constexpr int WL16 = 4 * 4 * NT * KS * 64;                         // 16-byte fragments of the lo plane (all waves)
+    constexpr int HB16 = 3 * KS * 64;                                  // ... of one buffer of h fragments
+    extern __shared__ __attribute__((aligned(16))) unsigned char lstm_lds[];
+    uint4* const wl = reinterpret_cast<uint4*>(lstm_lds);              // [wave][gate][sub-tile][k-step][lane]
+    uint4* const hp = wl + WL16;                                       // [buffer][piece][k-step][slot = 16 kgroup + sequence]
+    const int dir = blockIdx.y, n0 = blockIdx.x * NSEQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, rg = lane >> 4;
+    const int n = n0 + col;
+    const bool nv = n < N;
+    const int nc = min(n, N - 1);
+    const float* W = whh + (size_t)dir * 4 * H * H;
+
+    // A fragments of this wave's gate rows: tile (gate g, sub-tile s), k-step ks: A[m = lane & 15][k = 32 ks + 8 (lane >> 4) + j]
+    lstm_frag wh[4][NT][KS], wm[4][NT][KS];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int u = wave * UPW + 16 * s + (lane & 15);
+                lstm_frag lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 32 * ks + 8 * rg + 2 * j;
+                    const float w0 = (u < H && k < H) ? W[((size_t)g * H + u) * H + k] : 0.f;
+                    const float w1 = (u < H && k + 1 < H) ? W[((size_t)g * H + u) * H + k + 1] : 0.f;
+                    lstm_split2(w0, w1, wh[g][s][ks].u[j], wm[g][s][ks].u[j], lo.u[j]);
+                }
+                wl[(((wave * 4 + g) * NT + s) * KS + ks) * 64 + lane] = uint4{lo.u[0], lo.u[1], lo.u[2], lo.u[3]};
+            }
+    // The weights take the accumulation registers, all 256 of them (the matrix instruction reads its A operand from
+    // either file); left to itself the allocator fills the vector registers with them and then shuffles everything
+    // else of the step through the accumulation registers, waiting for each prefetched load right behind its issue.
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                asm volatile("" : "+a"(wh[g][s][ks].v));
+                asm volatile("" : "+a"(wm[g][s][ks].v));
+            }
+    int ub[NT];
+    bool uv[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        ub[s] = wave * UPW + 16 * s + 4 * rg;
+        uv[s] = ub[s] < H;
+    }
+    float c[NT][4];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[s][e] = 0.f;
+    for (int i = tid; i < HB16; i += NTH) hp[i] = uint4{0u, 0u, 0u, 0u};          // h_{-1} = 0
+
+    const int64_t row_x = (int64_t)D * 4 * H;
+    auto load_x = [&](int t, f32x4 (&xp)[4][NT]) {
+        const float* base = xproj + ((int64_t)nc * T + t) * row_x + (int64_t)dir * 4 * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                xp[g][s] = ctn_ld4(base + g * H + (uv[s] ? ub[s] : 0));           // units past H: zeroed where it is used
+            }
+    };
+    f32x4 xp[4][NT];
+    load_x(dir == 0 ? 0 : T - 1, xp);
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[g][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // next step's input projection, a whole step ahead of its use (the last step reads its own row again)
+        f32x4 xn[4][NT];
+#ifndef CTN_DBG_LSTM_NO_LOADX
+        load_x(step + 1 < T ? (dir == 0 ? t + 1 : t - 1) : t, xn);
+#else
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < NT; ++s) xn[g][s] = xp[g][s];
+#endif
+        const uint4* hb = hp + (step & 1) * HB16;
+        // h fragments of k-step ks + 1 are read from LDS while the matrix unit works on k-step ks; the lo plane of W_hh
+        // feeds the first product only, so one set of registers serves: it is refilled right behind that product
+        lstm_frag bh[2], bm[2], bl[2], lo[4][NT];
+        auto read_h = [&](int ks, int b) {
+            const uint4 v0 = hb[(0 * KS + ks) * 64 + lane], v1 = hb[(1 * KS + ks) * 64 + lane], v2 = hb[(2 * KS + ks) * 64 + lane];
+            bh[b].u[0] = v0.x, bh[b].u[1] = v0.y, bh[b].u[2] = v0.z, bh[b].u[3] = v0.w;
+            bm[b].u[0] = v1.x, bm[b].u[1] = v1.y, bm[b].u[2] = v1.z, bm[b].u[3] = v1.w;
+            bl[b].u[0] = v2.x, bl[b].u[1] = v2.y, bl[b].u[2] = v2.z, bl[b].u[3] = v2.w;
+        };
+        auto read_lo = [&](int ks) {
+#ifndef CTN_DBG_LSTM_NO_LO
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int s = 0; s < NT; ++s) {
+                    const uint4 v = wl[(((wave * 4 + g) * NT + s) * KS + ks) * 64 + lane];
+                    lo[g][s].u[0] = v.x, lo[g][s].u[1] = v.y, lo[g][s].u[2] = v.z, lo[g][s].u[3] = v.w;
+                }
+#endif
+        };
+        read_h(0, 0);
+        read_lo(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cb = ks & 1;
+            // smallest products first; the eight tiles alternate, so consecutive instructions are independent
+#define CTN_LSTM_MFMA(A_, B_)                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int s = 0; s < NT; ++s)                  \
+        acc[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[g][s] CTN_LSTM_KS .v, B_[cb].v, acc[g][s], 0, 0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+#define CTN_LSTM_KS
+#ifndef CTN_DBG_LSTM_NO_LO
+            CTN_LSTM_MFMA(lo, bh);
+#endif
+#undef CTN_LSTM_KS
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < KS) {
+                read_lo(ks + 1);
+                read_h(ks + 1, cb ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define CTN_LSTM_KS [ks]
+#ifndef CTN_DBG_LSTM_NO_MMA
+            CTN_LSTM_MFMA(wh, bl);
+            CTN_LSTM_MFMA(wm, bm);
+            CTN_LSTM_MFMA(wm, bh);
+            CTN_LSTM_MFMA(wh, bm);
+#endif
+            CTN_LSTM_MFMA(wh, bh);
+#undef CTN_LSTM_KS
+#undef CTN_LSTM_MFMA
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint4* hn = hp + ((step + 1) & 1) * HB16;
+        // the input projection joins after the matrix work
+        f32x4 xv[4][NT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < NT; ++s) xv[g][s] = (FULL || uv[s]) ? xp[g][s] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            f32x4 iv, fv, gv, ov, cv, hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#ifndef CTN_DBG_LSTM_NO_GATE
+                iv[e] = sigmoidf_(acc[0][s][e] + xv[0][s][e]);
+                fv[e] = sigmoidf_(acc[1][s][e] + xv[1][s][e]);
+                gv[e] = tanhf_(acc[2][s][e] + xv[2][s][e]);
+                ov[e] = sigmoidf_(acc[3][s][e] + xv[3][s][e]);
+                c[s][e] = fv[e] * c[s][e] + iv[e] * gv[e];
+                cv[e] = c[s][e];
+                hv[e] = ov[e] * tanhf_(c[s][e]);
+#else
+                iv[e] = acc[0][s][e]; fv[e] = acc[1][s][e]; gv[e] = acc[2][s][e]; ov[e] = acc[3][s][e];
+                c[s][e] = 0.5f * c[s][e] + 0.01f * iv[e] * gv[e];
+                cv[e] = c[s][e];
+                hv[e] = 0.01f * ov[e] * c[s][e];
+#endif
+            }
+            // this lane's four units of h_t as half a B fragment per piece: units ub[s] .. ub[s] + 3 of sequence `col`
+            {
+                unsigned h0, m0, l0, h1, m1, l1;
+                lstm_split2(hv[0], hv[1], h0, m0, l0);
+                lstm_split2(hv[2], hv[3], h1, m1, l1);
+                const int u = ub[s], ks = u >> 5, slot = ((u & 31) >> 3) * 16 + col, half8 = (u & 7) >> 2;
+                uint2* d0 = reinterpret_cast<uint2*>(hn + (0 * KS + ks) * 64 + slot) + half8;
+                uint2* d1 = reinterpret_cast<uint2*>(hn + (1 * KS + ks) * 64 + slot) + half8;
+                uint2* d2 = reinterpret_cast<uint2*>(hn + (2 * KS + ks) * 64 + slot) + half8;
+                *d0 = uint2{h0, h1};
+                *d1 = uint2{m0, m1};
+                *d2 = uint2{l0, l1};
+            }
+#ifdef CTN_DBG_LSTM_NO_STORE
+            if (nv && uv[s] && step == T - 1) {
+#else
+            if (FULL || (nv && uv[s])) {
+#endif
+                const int64_t o = ((int64_t)(FULL ? nc : n) * T + t) * D + dir;
+                ctn_st4(hout + o * H + ub[s], hv);
+                float* sv = save + o * 5 * H + ub[s];
+                ctn_st4(sv, iv);
+                ctn_st4(sv + H, fv);
+                ctn_st4(sv + 2 * H, gv);
+                ctn_st4(sv + 3 * H, ov);
+                ctn_st4(sv + 4 * H, cv);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < NT; ++s) xp[g][s] = xn[g][s];
+        __syncthreads();              // h_t complete in hn; every wave is done reading hb
+    }
+}
+
 // ------------------------------------------------------------------------------------------ backward through time
 template <int NT>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(
@@ -281,6 +523,33 @@ int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int 
     CTN_REQUIRE(lstm_args_ok(N, T, H, D), "ctn_lstm_fwd: needs hidden size <= 128 and a multiple of 4, 1 or 2 directions");
     CTN_REQUIRE(ctn_aligned16(xproj) && ctn_aligned16(hout) && ctn_aligned16(save), "ctn_lstm_fwd: 16-byte alignment");
     dim3 grid(ctn_cdiv(N, NSEQ), D);
+    static const bool f32_only = [] { const char* e = getenv("CTN_LSTM_F32"); return e && e[0] == '1'; }();
+    if (!f32_only) {
+        // recurrent product on the bf16 matrix instruction, exact three-piece split (dynamic LDS: the lo plane of W_hh
+        // and two buffers of h fragments)
+        const int NTv = H <= 64 ? 1 : 2;
+        const size_t shm = ((size_t)4 * 4 * NTv * (2 * NTv) * 64 + 2 * (size_t)3 * (2 * NTv) * 64) * 16;
+        static bool asked[64][2] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!asked[dev][NTv - 1]) {
+            const void* fns[3] = {reinterpret_cast<const void*>(lstm_fwd_b3_kernel<1, false>),
+                                  reinterpret_cast<const void*>(lstm_fwd_b3_kernel<2, false>),
+                                  reinterpret_cast<const void*>(lstm_fwd_b3_kernel<2, true>)};
+            for (int i = NTv - 1; i < (NTv == 1 ? 1 : 3); ++i)
+                CTN_REQUIRE(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess,
+                            "ctn_lstm_fwd: cannot raise the dynamic LDS limit");
+            asked[dev][NTv - 1] = true;
+        }
+        if (NTv == 1)
+            hipLaunchKernelGGL((lstm_fwd_b3_kernel<1, false>), grid, dim3(NTH), shm, (hipStream_t)stream, xproj, whh, hout, save, N, T, H, D);
+        else if (H == 128)
+            hipLaunchKernelGGL((lstm_fwd_b3_kernel<2, true>), grid, dim3(NTH), shm, (hipStream_t)stream, xproj, whh, hout, save, N, T, H, D);
+        else
+            hipLaunchKernelGGL((lstm_fwd_b3_kernel<2, false>), grid, dim3(NTH), shm, (hipStream_t)stream, xproj, whh, hout, save, N, T, H, D);
+        CTN_CHECK_LAUNCH("ctn_lstm_fwd");
+        return CTN_OK;
+    }
     if (H <= 64)
         hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, dim3(NTH), 0, (hipStream_t)stream, xproj, whh, hout, save, N, T, H, D);
     else

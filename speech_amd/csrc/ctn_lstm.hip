@@ -511,6 +511,189 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward, bf16 matrix unit
+// The reverse walk with dL/dh_{t-1} = W_hh^T . dgates_t on v_mfma_f32_16x16x32_bf16, same exact three-piece arithmetic as
+// the forward kernel.  W_hh^T's hi and mid pieces fill the accumulation registers as A fragments; of the lo pieces the
+// first KR k-steps stay in vector registers and the rest live in LDS (96 KB at hidden size 128), because the step's gate
+// gradients, split by the lanes that compute them, need 48 KB of LDS as B fragments.  One set of registers holds a
+// step's saved tensors: the next step's are requested right behind the gate arithmetic and arrive during the matrix phase.
+template <int NT, bool FULL>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_b3_kernel(
+    const float* __restrict__ dhout, const float* __restrict__ save, const float* __restrict__ whh,
+    float* __restrict__ dgates, const int N, const int T, const int H, const int D) {
+    constexpr int HP = 64 * NT, ROWS = 4 * HP, KS = ROWS / 32, UPW = 16 * NT;
+    constexpr int KR = NT == 2 ? 4 : 0;                                // k-steps whose lo fragments stay in registers
+    constexpr int KL = KS - KR;
+    constexpr int WL16 = 4 * NT * KL * 64;                             // 16-byte fragments of the lo plane in LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char lstm_lds[];
+    uint4* const wl = reinterpret_cast<uint4*>(lstm_lds);              // [wave][sub-tile][k-step - KR][lane]
+    uint4* const dgp = wl + WL16;                                      // [piece][k-step][slot = 16 kgroup + sequence]
+    const int dir = blockIdx.y, n0 = blockIdx.x * NSEQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, rg = lane >> 4;
+    const int n = n0 + col;
+    const bool nv = n < N;
+    const int nc = min(n, N - 1);
+    const float* W = whh + (size_t)dir * 4 * H * H;
+
+    // A fragments of W_hh^T: tile s (units wave UPW + 16 s + (lane & 15)), k-step ks: k = padded gate row 32 ks + 8 (lane >> 4) + j
+    lstm_frag wh[NT][KS], wm[NT][KS], lor[NT][KR > 0 ? KR : 1];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int u = wave * UPW + 16 * s + (lane & 15);
+            lstm_frag lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 32 * ks + 8 * rg + 2 * j, g = r / HP, ur = r % HP;      // r even: r and r + 1 share the gate
+                const float w0 = (u < H && ur < H) ? W[((size_t)g * H + ur) * H + u] : 0.f;
+                const float w1 = (u < H && ur + 1 < H) ? W[((size_t)g * H + ur + 1) * H + u] : 0.f;
+                lstm_split2(w0, w1, wh[s][ks].u[j], wm[s][ks].u[j], lo.u[j]);
+            }
+            if (ks < KR)
+                lor[s][ks < KR ? ks : 0] = lo;
+            else
+                wl[((wave * NT + s) * KL + (ks - KR)) * 64 + lane] = uint4{lo.u[0], lo.u[1], lo.u[2], lo.u[3]};
+        }
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            asm volatile("" : "+a"(wh[s][ks].v));
+            asm volatile("" : "+a"(wm[s][ks].v));
+        }
+    int ub[NT];
+    bool uv[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        ub[s] = wave * UPW + 16 * s + 4 * rg;
+        uv[s] = ub[s] < H;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dh_rec[NT], dc_carry[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) dh_rec[s] = dc_carry[s] = zero4;
+
+    // what one step reads: the five saved tensors at t, the cell state of the step before t in forward order, dL/dh_t.
+    // Raw loads only: what must be zero (units past H, no predecessor) is zeroed where it is used, so nothing waits here.
+    f32x4 sv[5][NT], cp[NT], dho[NT];
+    auto load_step = [&](int t) {
+        const int tp = dir == 0 ? t - 1 : t + 1;                       // forward-order predecessor
+        const bool has_prev = tp >= 0 && tp < T;
+        const int64_t o = ((int64_t)nc * T + t) * D + dir;
+        const int64_t op = ((int64_t)nc * T + (has_prev ? tp : t)) * D + dir;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int u0 = uv[s] ? ub[s] : 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) sv[q][s] = ctn_ld4(save + o * 5 * H + q * H + u0);
+            cp[s] = ctn_ld4(save + op * 5 * H + 4 * H + u0);
+            dho[s] = ctn_ld4(dhout + o * H + u0);
+        }
+    };
+    load_step(dir == 0 ? T - 1 : 0);
+    __syncthreads();                  // lo plane in place
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;                  // the reverse of the forward walk
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const bool has_prev = tp >= 0 && tp < T;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            f32x4 dgv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = FULL || uv[s];
+                const float iv = sv[0][s][e], fv = sv[1][s][e], gv = sv[2][s][e], ov = sv[3][s][e];
+                const float tc = tanhf_(sv[4][s][e]);
+                const float dh = (ok ? dho[s][e] : 0.f) + dh_rec[s][e];
+                const float dc = dh * ov * (1.f - tc * tc) + dc_carry[s][e];
+                const float cpe = has_prev ? cp[s][e] : 0.f;
+                dgv[3][e] = ok ? dh * tc * ov * (1.f - ov) : 0.f;
+                dgv[0][e] = ok ? dc * gv * iv * (1.f - iv) : 0.f;
+                dgv[2][e] = ok ? dc * iv * (1.f - gv * gv) : 0.f;
+                dgv[1][e] = ok ? dc * cpe * fv * (1.f - fv) : 0.f;
+                dc_carry[s][e] = ok ? dc * fv : 0.f;
+            }
+            // this lane's four units of each gate's gradient as half a B fragment per piece
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                lstm_split2(dgv[g][0], dgv[g][1], h0, m0, l0);
+                lstm_split2(dgv[g][2], dgv[g][3], h1, m1, l1);
+                const int r = g * HP + ub[s], ks = r >> 5, slot = ((r & 31) >> 3) * 16 + col, half8 = (r & 7) >> 2;
+                *(reinterpret_cast<uint2*>(dgp + (0 * KS + ks) * 64 + slot) + half8) = uint2{h0, h1};
+                *(reinterpret_cast<uint2*>(dgp + (1 * KS + ks) * 64 + slot) + half8) = uint2{m0, m1};
+                *(reinterpret_cast<uint2*>(dgp + (2 * KS + ks) * 64 + slot) + half8) = uint2{l0, l1};
+            }
+            if (FULL || (nv && uv[s])) {
+                float* o = dgates + (((int64_t)(FULL ? nc : n) * T + t) * D + dir) * 4 * H + ub[s];
+                ctn_st4(o, dgv[0]);
+                ctn_st4(o + H, dgv[1]);
+                ctn_st4(o + 2 * H, dgv[2]);
+                ctn_st4(o + 3 * H, dgv[3]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next step's tensors into the registers this step is done with (the last step reads its own again)
+        load_step(step + 1 < T ? (dir == 0 ? t - 1 : t + 1) : t);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();              // the step's gate gradients are complete in LDS
+
+        // dL/dh of the forward-order predecessor: W_hh^T . dgates; two partial sums per tile
+        f32x4 acc[NT][2];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) acc[s][0] = acc[s][1] = zero4;
+        lstm_frag bh[2], bm[2], bl[2], lo[2][NT];
+        auto read_b = [&](int ks, int b) {
+            const uint4 v0 = dgp[(0 * KS + ks) * 64 + lane], v1 = dgp[(1 * KS + ks) * 64 + lane], v2 = dgp[(2 * KS + ks) * 64 + lane];
+            bh[b].u[0] = v0.x, bh[b].u[1] = v0.y, bh[b].u[2] = v0.z, bh[b].u[3] = v0.w;
+            bm[b].u[0] = v1.x, bm[b].u[1] = v1.y, bm[b].u[2] = v1.z, bm[b].u[3] = v1.w;
+            bl[b].u[0] = v2.x, bl[b].u[1] = v2.y, bl[b].u[2] = v2.z, bl[b].u[3] = v2.w;
+        };
+        auto read_lo = [&](int ks, int b) {
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                if (ks < KR) {
+                    lo[b][s] = lor[s][ks < KR ? ks : 0];
+                } else {
+                    const uint4 v = wl[((wave * NT + s) * KL + (ks - KR)) * 64 + lane];
+                    lo[b][s].u[0] = v.x, lo[b][s].u[1] = v.y, lo[b][s].u[2] = v.z, lo[b][s].u[3] = v.w;
+                }
+            }
+        };
+        read_b(0, 0);
+        read_lo(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cb = ks & 1;
+            if (ks + 1 < KS) {
+                read_b(ks + 1, cb ^ 1);
+                read_lo(ks + 1, cb ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest products first; consecutive instructions alternate over the tiles and the two partial sums
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo[cb][s].v, bh[cb].v, acc[s][0], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s][ks].v, bl[cb].v, acc[s][1], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s][ks].v, bm[cb].v, acc[s][0], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s][ks].v, bh[cb].v, acc[s][1], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s][ks].v, bm[cb].v, acc[s][0], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s][ks].v, bh[cb].v, acc[s][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < NT; ++s) dh_rec[s] = acc[s][0] + acc[s][1];
+        __syncthreads();              // every wave is done reading the fragments before the next step overwrites them
+    }
+}
+
 bool lstm_args_ok(int N, int T, int H, int D) { return N > 0 && T > 0 && H > 0 && H <= 128 && H % 4 == 0 && (D == 1 || D == 2); }
 
 }  // namespace
@@ -564,6 +747,32 @@ int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N,
     CTN_REQUIRE(lstm_args_ok(N, T, H, D), "ctn_lstm_bwd: needs hidden size <= 128 and a multiple of 4, 1 or 2 directions");
     CTN_REQUIRE(ctn_aligned16(dhout) && ctn_aligned16(dgates) && ctn_aligned16(save), "ctn_lstm_bwd: 16-byte alignment");
     dim3 grid(ctn_cdiv(N, NSEQ), D);
+    static const bool f32_only = [] { const char* e = getenv("CTN_LSTM_F32"); return e && e[0] == '1'; }();
+    if (!f32_only) {
+        const int NTv = H <= 64 ? 1 : 2;
+        const int KSv = 8 * NTv, KRv = NTv == 2 ? 4 : 0;
+        const size_t shm = ((size_t)4 * NTv * (KSv - KRv) * 64 + (size_t)3 * KSv * 64) * 16;
+        static bool asked[64][2] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!asked[dev][NTv - 1]) {
+            const void* fns[3] = {reinterpret_cast<const void*>(lstm_bwd_b3_kernel<1, false>),
+                                  reinterpret_cast<const void*>(lstm_bwd_b3_kernel<2, false>),
+                                  reinterpret_cast<const void*>(lstm_bwd_b3_kernel<2, true>)};
+            for (int i = NTv - 1; i < (NTv == 1 ? 1 : 3); ++i)
+                CTN_REQUIRE(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess,
+                            "ctn_lstm_bwd: cannot raise the dynamic LDS limit");
+            asked[dev][NTv - 1] = true;
+        }
+        if (NTv == 1)
+            hipLaunchKernelGGL((lstm_bwd_b3_kernel<1, false>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+        else if (H == 128)
+            hipLaunchKernelGGL((lstm_bwd_b3_kernel<2, true>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+        else
+            hipLaunchKernelGGL((lstm_bwd_b3_kernel<2, false>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+        CTN_CHECK_LAUNCH("ctn_lstm_bwd");
+        return CTN_OK;
+    }
     if (H <= 64)
         hipLaunchKernelGGL(lstm_bwd_kernel<1>, grid, dim3(NTH), 0, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
     else

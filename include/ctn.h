@@ -153,6 +153,17 @@ int ctn_overlap_add(const float* y, int batch, int C, int S, int K, int P, int p
                     int64_t ldx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Axis shuffles of the dual-path blocks (src/models/dprnn.py:83,88 inside chunks; :135,140,144-146 across chunks:
+ * permute(...).contiguous() between (batch, features, S, K) and the recurrences' (sequences, steps, features) rows, and
+ * the residual sum behind the last of them), as batched strided 2-D transposes of fp32:
+ *   dst[b2][b1][k][m] = src[b2][b1][m][k] (+ addend[b2][b1][k][m] when addend is not null)
+ * for m < M, k < K, b1 < nb1, b2 < nb2; source rows are lds floats apart and destination rows ldd, sb1/sb2 and db1/db2
+ * are the batch strides on the two sides; addend and dst share a layout and may be the same buffer.  nb1 * nb2 <= 65535.
+ * ------------------------------------------------------------------------------------------- */
+int ctn_permute(const float* src, float* dst, const float* addend, int M, int K, int64_t lds, int64_t ldd, int nb1,
+                int64_t sb1, int64_t db1, int nb2, int64_t sb2, int64_t db2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * LSTM recurrence over whole sequences in one launch: the nn.LSTM(batch_first=True) of the dual-path blocks
  * (src/models/dprnn.py:60,85 inside chunks, :104-114,137 across chunks; gate order i, f, g, o as in torch), one or two
  * directions, zero initial state.  The caller hoists the input projection out of the recurrence:
@@ -163,7 +174,9 @@ int ctn_overlap_add(const float* y, int batch, int C, int S, int K, int P, int p
  * ctn_lstm_bwd walks the steps in the opposite order: from dhout (N, T, D, H) = dL/dh_t and `save` it writes
  *   dgates (N, T, D, 4H)  dL/d(gate pre-activations) = dL/dxproj,
  * from which the weight, bias and input gradients are plain GEMMs / sums over (N, T).
- * H <= 128 and H % 4 == 0; all tensors dense and 16-byte aligned; fp32 throughout (f32 MFMA).
+ * H <= 128 and H % 4 == 0; all tensors dense and 16-byte aligned; fp32 in and out.  The recurrent products run on the
+ * bf16 matrix instruction in the exact three-piece split of CTN_ARITH_BF16X3 (fp32 accumulation); the environment
+ * variable CTN_LSTM_F32=1, read once, selects the f32 matrix instruction instead.
  * ------------------------------------------------------------------------------------------- */
 int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int D, float* hout, float* save,
                  void* stream);

@@ -146,6 +146,7 @@ PROTOTYPES = {
     "ctn_probe_mfma_f32": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "ctn_probe_mfma_bf16": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "ctn_transpose": (C.c_int, [_p, C.c_int, C.c_int, _p, _i64, _i64, _p]),
+    "ctn_permute": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _i64, _i64, C.c_int, _i64, _i64, C.c_int, _i64, _i64, _p]),
     "ctn_sizeof_wprep_item": (C.c_int, []),
     "ctn_sizeof_transpose_item": (C.c_int, []),
     "ctn_transpose_batch": (C.c_int, [C.POINTER(TransposeItem), C.c_int, _p]),

@@ -479,6 +479,57 @@ class LstmFn(torch.autograd.Function):
         return (dx, None) + tuple(grads)
 
 
+# ------------------------------------------------------------------------------------------------ axis shuffles of the dual-path blocks
+class RowsFromBlocksFn(torch.autograd.Function):
+    """(B, F, S, K) -> the recurrence's rows (B*S, K, F) (walk_chunks False) or (B*K, S, F) (True), i.e.
+    input.permute(0, 2, 3, 1) / permute(0, 3, 2, 1) made contiguous (src/models/dprnn.py:83-84, :135-136), as one
+    tiled transpose; the gradient takes the inverse one and comes back contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, walk_chunks):
+        ops._require_cuda(x)
+        ctx.walk = walk_chunks
+        r = ops.rows_from_blocks(x.detach().float().contiguous(), walk_chunks)
+        ctx.rshape = r.shape
+        return r.view(r.shape[0] * r.shape[1], r.shape[2], r.shape[3])
+
+    @staticmethod
+    def backward(ctx, dr):
+        return ops.blocks_from_rows(dr.contiguous().float().view(ctx.rshape), ctx.walk), None
+
+
+class FeatureFirstFn(torch.autograd.Function):
+    """(B, L, F) -> (B, F, L) (src/models/dprnn.py:88, :140), written in the layout the norm kernels read."""
+
+    @staticmethod
+    def forward(ctx, r):
+        ops._require_cuda(r)
+        return ops.feature_first(r.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.float()
+        return ops.feature_last(g if g.stride(2) == 1 else g.contiguous())
+
+
+class SwapAddFn(torch.autograd.Function):
+    """z (B, F, K, S), x (B, F, S, K) -> z.permute(0, 1, 3, 2) + x (src/models/dprnn.py:144-146) in one pass."""
+
+    @staticmethod
+    def forward(ctx, z, x):
+        ops._require_cuda(z, x)
+        z = z.detach().float()
+        if z.stride(3) != 1 or z.stride(2) != z.shape[3]:
+            z = z.contiguous()
+        return ops.swap_blocks(z, addend=x.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous().float()
+        dz = ops.swap_blocks(dout, act=True) if ctx.needs_input_grad[0] else None
+        return dz, dout if ctx.needs_input_grad[1] else None
+
+
 # ------------------------------------------------------------------------------------------------ chunking
 class SegmentFn(torch.autograd.Function):
     """Segment1d.forward (src/models/transform.py:15-31) of the input zero-padded by (pad_left, as far as S chunks reach):

@@ -9,12 +9,13 @@ cumulative norm).
 The recurrence runs on this package's persistent LSTM kernels (`LSTM` below: nn.LSTM's parameters, ctn_lstm_fwd/bwd
 through speech_amd.functional.LstmFn) -- one launch per sequence walk instead of two library launches per time step --
 with the input projection of all steps and the weight gradients as single large GEMMs.  The norms are this package's
-kernels as well; the linear layer is torch's (a plain library GEMM), the axis shuffles are tensor operations.
+kernels as well, and so are the axis shuffles between the two layouts (tiled transposes, ctn_permute); the linear layer
+is torch's (a plain library GEMM).
 """
 import torch.nn as nn
 
 from .. import ops
-from ..functional import LinearFn, LstmFn
+from ..functional import FeatureFirstFn, LinearFn, LstmFn, RowsFromBlocksFn, SwapAddFn
 from ..utils.tasnet import choose_layer_norm
 
 EPS = 1e-12
@@ -64,18 +65,16 @@ class _PathRNN(nn.Module):
 
     def forward(self, input):
         batch_size, num_features, S, K = input.size()
-        # (batch, features, S, K) -> (sequences, steps, features)
-        order = (0, 3, 2, 1) if self.walk_chunks else (0, 2, 3, 1)
         outer, steps = (K, S) if self.walk_chunks else (S, K)
-        sequences = input.permute(*order).reshape(batch_size * outer, steps, num_features)
+        sequences = RowsFromBlocksFn.apply(input, self.walk_chunks)        # (batch * outer, steps, features)
         y, _ = self.rnn(sequences)
         y = LinearFn.apply(y, self.fc.weight, self.fc.bias)                # (sequences, steps, features)
-        y = y.view(batch_size, outer * steps, num_features).permute(0, 2, 1).contiguous()
+        y = FeatureFirstFn.apply(y.view(batch_size, outer * steps, num_features))      # (batch, features, outer * steps)
         if self.norm:
-            y = self.norm1d(y)                                             # over (features, outer * steps)
-        y = y.reshape(batch_size, num_features, outer, steps)
+            y = self.norm1d(y)
+        y = y.view(batch_size, num_features, outer, steps)
         if self.walk_chunks:
-            y = y.permute(0, 1, 3, 2)                                      # back to (batch, features, S, K)
+            return SwapAddFn.apply(y, input)                               # back to (batch, features, S, K), plus input
         return y + input
 
 

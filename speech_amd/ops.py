@@ -291,6 +291,79 @@ def lstm_bwd(dhout, save, whh):
     return dgates
 
 
+# ------------------------------------------------------------------------------------------------ axis shuffles
+def _reaches(t, last):
+    """True if element offset `last` (from t's first element) lies inside t's storage."""
+    return t.storage_offset() + last < t.untyped_storage().nbytes() // 4
+
+
+def permute(src, dst, M, K, lds, ldd, nb1=1, sb1=0, db1=0, nb2=1, sb2=0, db2=0, addend=None):
+    """dst[b2][b1][k][m] = src[b2][b1][m][k] (+ addend, laid out like dst); strides in elements from the tensors' first
+    elements; see ctn_permute."""
+    lib = _lib.load()
+    _require_cuda(src, dst, addend)
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32
+    assert addend is None or (addend.dtype == torch.float32 and addend.stride() == dst.stride() and addend.shape == dst.shape)
+    last_src = (nb2 - 1) * sb2 + (nb1 - 1) * sb1 + (M - 1) * lds + K - 1
+    last_dst = (nb2 - 1) * db2 + (nb1 - 1) * db1 + (K - 1) * ldd + M - 1
+    assert _reaches(src, last_src) and _reaches(dst, last_dst), "permute: strides reach outside the tensors"
+    _lib.check(lib.ctn_permute(_ptr(src), _ptr(dst), _ptr(addend) if addend is not None else None, M, K, lds, ldd, nb1, sb1,
+                               db1, nb2, sb2, db2, _stream()), "ctn_permute")
+    return dst
+
+
+def rows_from_blocks(x, walk_chunks):
+    """(B, F, S, K) contiguous -> (B, S, K, F) (walk_chunks False) or (B, K, S, F) (True): the recurrences' rows."""
+    B, F_, S, K = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, K, S, F_) if walk_chunks else (B, S, K, F_), device=x.device, dtype=torch.float32)
+    if walk_chunks:         # per (b, s): (F, K) -> (K, F)
+        return permute(x, y, F_, K, S * K, S * F_, nb1=S, sb1=K, db1=F_, nb2=B, sb2=F_ * S * K, db2=F_ * S * K)
+    return permute(x, y, F_, S * K, S * K, F_, nb1=B, sb1=F_ * S * K, db1=F_ * S * K)
+
+
+def blocks_from_rows(r, walk_chunks):
+    """Inverse of rows_from_blocks: (B, S, K, F) or (B, K, S, F) contiguous -> (B, F, S, K)."""
+    assert r.is_contiguous()
+    if walk_chunks:
+        B, K, S, F_ = r.shape
+        x = torch.empty((B, F_, S, K), device=r.device, dtype=torch.float32)
+        return permute(r, x, K, F_, S * F_, S * K, nb1=S, sb1=F_, db1=K, nb2=B, sb2=F_ * S * K, db2=F_ * S * K)
+    B, S, K, F_ = r.shape
+    x = torch.empty((B, F_, S, K), device=r.device, dtype=torch.float32)
+    return permute(r, x, S * K, F_, F_, S * K, nb1=B, sb1=F_ * S * K, db1=F_ * S * K)
+
+
+def feature_first(r):
+    """(B, L, F) contiguous -> (B, F, L) in the activation layout (16-byte rows) the norm kernels read."""
+    B, L, F_ = r.shape
+    assert r.is_contiguous()
+    y = new_act(B, F_, L, r.device)
+    return permute(r, y, L, F_, F_, y.stride(1), nb1=B, sb1=L * F_, db1=y.stride(0))
+
+
+def feature_last(g):
+    """(B, F, L) with unit stride along L -> (B, L, F) contiguous."""
+    B, F_, L = g.shape
+    assert g.stride(2) == 1
+    y = torch.empty((B, L, F_), device=g.device, dtype=torch.float32)
+    return permute(g, y, F_, L, g.stride(1), F_, nb1=B, sb1=g.stride(0), db1=L * F_)
+
+
+def swap_blocks(z, addend=None, act=False):
+    """(B, F, P, Q) with contiguous (P, Q) planes -> (B, F, Q, P) (+ addend of that shape).  act=True lays the result
+    out as a (B, F, Q*P) activation (16-byte rows) and returns its (B, F, Q, P) view."""
+    B, F_, P, Q = z.shape
+    assert z.stride(3) == 1 and z.stride(2) == Q and B * F_ <= 65535
+    if act:
+        flat = new_act(B, F_, Q * P, z.device)
+        y = flat.view(B, F_, Q, P)
+    else:
+        y = torch.empty((B, F_, Q, P), device=z.device, dtype=torch.float32)
+    return permute(z, y, P, Q, Q, P, nb1=F_, sb1=z.stride(1), db1=y.stride(1), nb2=B, sb2=z.stride(0), db2=y.stride(0),
+                   addend=addend)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 def transpose(src2d, dst, ldd, coff=0):
     lib = _lib.load()

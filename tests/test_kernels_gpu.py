@@ -99,6 +99,33 @@ def test_transpose_batch():
     assert torch.equal(both, torch.cat([a, b], 0).t())
 
 
+@pytest.mark.parametrize("B,F,S,K", [(2, 5, 7, 9), (3, 64, 33, 50), (1, 64, 31, 125), (2, 33, 1, 70)])
+def test_dual_path_axis_shuffles(B, F, S, K):
+    """ctn_permute through its five callers against torch's permute: bit-exact (copies, one addition)."""
+    from speech_amd import ops
+    x = rnd((B, F, S, K), 11).float().to(dev())
+    for walk in (False, True):
+        want = x.permute(0, 3, 2, 1) if walk else x.permute(0, 2, 3, 1)
+        r = ops.rows_from_blocks(x, walk)
+        assert r.is_contiguous() and torch.equal(r, want.contiguous())
+        assert torch.equal(ops.blocks_from_rows(r, walk), x)
+    rows = rnd((B, S * K, F), 12).float().to(dev())
+    ff = ops.feature_first(rows)                                           # activation layout: rows padded to 16 bytes
+    assert ops.is_act(ff) and torch.equal(ff, rows.permute(0, 2, 1))
+    assert torch.equal(ops.feature_last(ff), rows)
+    assert torch.equal(ops.feature_last(rows.permute(0, 2, 1).contiguous()), rows)
+    z = ops.new_act(B, F, K * S, dev())
+    z.copy_(rnd((B, F, K * S), 13).float())
+    z4 = z.view(B, F, K, S)
+    assert torch.equal(ops.swap_blocks(z4), z4.permute(0, 1, 3, 2).contiguous())
+    assert torch.equal(ops.swap_blocks(z4, addend=x), z4.permute(0, 1, 3, 2) + x)
+    back = ops.swap_blocks(x, act=True)                                    # (B, F, K, S) view of an activation
+    assert ops.is_act(back.reshape(B, F, K * S)) and back.reshape(B, F, K * S).data_ptr() == back.data_ptr()
+    assert torch.equal(back, x.permute(0, 1, 3, 2))
+    with pytest.raises(AssertionError):
+        ops.permute(x, torch.empty(4, device=dev()), F, K, S * K, F)       # strides beyond the destination
+
+
 @pytest.mark.parametrize("M,K,T,batch", [(40, 24, 301, 2), (128, 128, 515, 2), (200, 130, 257, 1), (512, 128, 3999, 1),
                                          (32, 512, 100, 3), (64, 64, 64, 1)])
 @pytest.mark.parametrize("width", [64, 128])

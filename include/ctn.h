@@ -173,7 +173,9 @@ int ctn_permute(const float* src, float* dst, const float* addend, int M, int K,
  *   save   (N, T, D, 5, H) i, f, g, o after their non-linearities and the cell state c_t, for ctn_lstm_bwd
  * ctn_lstm_bwd walks the steps in the opposite order: from dhout (N, T, D, H) = dL/dh_t and `save` it writes
  *   dgates (N, T, D, 4H)  dL/d(gate pre-activations) = dL/dxproj,
- * from which the weight, bias and input gradients are plain GEMMs / sums over (N, T).
+ *   dbias  (D, 4H)        its sum over (N, T) = dL/d(b_ih) = dL/d(b_hh); may be null (not formed); cleared by the call,
+ *                         accumulated with float atomics (summation order varies from run to run)
+ * from which the weight and input gradients are plain GEMMs over (N, T).
  * H <= 128 and H % 4 == 0; all tensors dense and 16-byte aligned; fp32 in and out.  The recurrent products run on the
  * bf16 matrix instruction in the exact three-piece split of CTN_ARITH_BF16X3 (fp32 accumulation); the environment
  * variable CTN_LSTM_F32=1, read once, selects the f32 matrix instruction instead.
@@ -181,7 +183,7 @@ int ctn_permute(const float* src, float* dst, const float* addend, int M, int K,
 int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int D, float* hout, float* save,
                  void* stream);
 int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N, int T, int H, int D, float* dgates,
-                 void* stream);
+                 float* dbias, void* stream);
 
 /* Finishing a global layer norm's reduction inside the launch that produces its sums (field `fin` of the argument structs
  * below; it applies to that launch's `esums` / `isums`).  With `count` given, the block that adds the LAST partial sums

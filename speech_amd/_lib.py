@@ -155,7 +155,7 @@ PROTOTYPES = {
     "ctn_segment": (C.c_int, [_p, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "ctn_overlap_add": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _i64, _i64, _p]),
     "ctn_lstm_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
-    "ctn_lstm_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "ctn_lstm_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "ctn_gemm_nn": (C.c_int, [C.POINTER(GemmNNArgs), _p]),
     "ctn_gemm_nt": (C.c_int, [C.POINTER(GemmNTArgs), _p]),
     "ctn_norm_stats": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _i64, _p, _p, _p, _i64, _p]),

@@ -397,11 +397,32 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// Bias gradient of one direction: each lane's per-step sums (its sequence, its four units of every gate) are added over
+// the block's 16 sequences (lanes that differ in their low four bits) and one lane in 16 adds the block's share to
+// dbias[gate * H + unit] (vector-memory float atomics).  Padded sequences do not take part.
+template <int NT>
+__device__ __forceinline__ void lstm_bias_grad(f32x4 (&dbs)[NT][4], float* __restrict__ dbias, const bool nv,
+                                               const bool (&uv)[NT], const int (&ub)[NT], const int H, const int lane) {
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = nv ? dbs[s][g][e] : 0.f;
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if ((lane & 15) == 0 && uv[s]) atomicAdd(dbias + g * H + ub[s] + e, v);
+            }
+}
+
 // ------------------------------------------------------------------------------------------ backward through time
 template <int NT>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(
     const float* __restrict__ dhout, const float* __restrict__ save, const float* __restrict__ whh,
-    float* __restrict__ dgates, const int N, const int T, const int H, const int D) {
+    float* __restrict__ dgates, float* __restrict__ dbias, const int N, const int T, const int H, const int D) {
     constexpr int HP = 64 * NT, ROWS = 4 * HP, KS = ROWS / 4, UPW = 16 * NT;
     __shared__ float dgbuf[ROWS * NSEQ];                               // gate gradients of this step: [padded row][sequence]
     const int dir = blockIdx.y, n0 = blockIdx.x * NSEQ;
@@ -430,9 +451,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         uv[s] = ub[s] < H;
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 dh_rec[NT], dc_carry[NT];
+    f32x4 dh_rec[NT], dc_carry[NT], dbs[NT][4];
 #pragma unroll
-    for (int s = 0; s < NT; ++s) dh_rec[s] = dc_carry[s] = zero4;
+    for (int s = 0; s < NT; ++s) {
+        dh_rec[s] = dc_carry[s] = zero4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbs[s][g] = zero4;
+    }
 
     // what one step reads: the five saved tensors at t, the cell state of the step before t in forward order, dL/dh_t
     struct StepIn {
@@ -483,6 +508,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 dgbuf[(2 * HP + ub[s] + e) * NSEQ + col] = dg[e];
                 dgbuf[(3 * HP + ub[s] + e) * NSEQ + col] = dob[e];
             }
+            dbs[s][0] += di;
+            dbs[s][1] += df;
+            dbs[s][2] += dg;
+            dbs[s][3] += dob;
             if (nv && uv[s]) {
                 float* o = dgates + (((int64_t)n * T + t) * D + dir) * 4 * H + ub[s];
                 ctn_st4(o, di);
@@ -509,6 +538,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         cur = nxt;
         __syncthreads();              // every wave is done reading dgbuf before the next step overwrites it
     }
+    if (dbias) lstm_bias_grad<NT>(dbs, dbias + (size_t)dir * 4 * H, nv, uv, ub, H, lane);
 }
 
 // ------------------------------------------------------------------------------------------ backward, bf16 matrix unit
@@ -520,7 +550,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int NT, bool FULL>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_b3_kernel(
     const float* __restrict__ dhout, const float* __restrict__ save, const float* __restrict__ whh,
-    float* __restrict__ dgates, const int N, const int T, const int H, const int D) {
+    float* __restrict__ dgates, float* __restrict__ dbias, const int N, const int T, const int H, const int D) {
     constexpr int HP = 64 * NT, ROWS = 4 * HP, KS = ROWS / 32, UPW = 16 * NT;
     constexpr int KR = NT == 2 ? 4 : 0;                                // k-steps whose lo fragments stay in registers
     constexpr int KL = KS - KR;
@@ -571,9 +601,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         uv[s] = ub[s] < H;
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 dh_rec[NT], dc_carry[NT];
+    f32x4 dh_rec[NT], dc_carry[NT], dbs[NT][4];                        // dbs: this lane's gate gradients summed over the steps
 #pragma unroll
-    for (int s = 0; s < NT; ++s) dh_rec[s] = dc_carry[s] = zero4;
+    for (int s = 0; s < NT; ++s) {
+        dh_rec[s] = dc_carry[s] = zero4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbs[s][g] = zero4;
+    }
 
     // what one step reads: the five saved tensors at t, the cell state of the step before t in forward order, dL/dh_t.
     // Raw loads only: what must be zero (units past H, no predecessor) is zeroed where it is used, so nothing waits here.
@@ -619,6 +653,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // this lane's four units of each gate's gradient as half a B fragment per piece
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                dbs[s][g] += dgv[g];
                 unsigned h0, m0, l0, h1, m1, l1;
                 lstm_split2(dgv[g][0], dgv[g][1], h0, m0, l0);
                 lstm_split2(dgv[g][2], dgv[g][3], h1, m1, l1);
@@ -692,6 +727,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int s = 0; s < NT; ++s) dh_rec[s] = acc[s][0] + acc[s][1];
         __syncthreads();              // every wave is done reading the fragments before the next step overwrites them
     }
+    if (dbias) lstm_bias_grad<NT>(dbs, dbias + (size_t)dir * 4 * H, nv, uv, ub, H, lane);
 }
 
 bool lstm_args_ok(int N, int T, int H, int D) { return N > 0 && T > 0 && H > 0 && H <= 128 && H % 4 == 0 && (D == 1 || D == 2); }
@@ -742,11 +778,14 @@ int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int 
 }
 
 int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N, int T, int H, int D, float* dgates,
-                 void* stream) {
+                 float* dbias, void* stream) {
     CTN_REQUIRE(dhout && save && whh && dgates, "ctn_lstm_bwd: null pointer");
     CTN_REQUIRE(lstm_args_ok(N, T, H, D), "ctn_lstm_bwd: needs hidden size <= 128 and a multiple of 4, 1 or 2 directions");
     CTN_REQUIRE(ctn_aligned16(dhout) && ctn_aligned16(dgates) && ctn_aligned16(save), "ctn_lstm_bwd: 16-byte alignment");
     dim3 grid(ctn_cdiv(N, NSEQ), D);
+    if (dbias)
+        CTN_REQUIRE(hipMemsetAsync(dbias, 0, sizeof(float) * D * 4 * H, (hipStream_t)stream) == hipSuccess,
+                    "ctn_lstm_bwd: cannot clear the bias gradient");
     static const bool f32_only = [] { const char* e = getenv("CTN_LSTM_F32"); return e && e[0] == '1'; }();
     if (!f32_only) {
         const int NTv = H <= 64 ? 1 : 2;
@@ -765,18 +804,18 @@ int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N,
             asked[dev][NTv - 1] = true;
         }
         if (NTv == 1)
-            hipLaunchKernelGGL((lstm_bwd_b3_kernel<1, false>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+            hipLaunchKernelGGL((lstm_bwd_b3_kernel<1, false>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, dbias, N, T, H, D);
         else if (H == 128)
-            hipLaunchKernelGGL((lstm_bwd_b3_kernel<2, true>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+            hipLaunchKernelGGL((lstm_bwd_b3_kernel<2, true>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, dbias, N, T, H, D);
         else
-            hipLaunchKernelGGL((lstm_bwd_b3_kernel<2, false>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+            hipLaunchKernelGGL((lstm_bwd_b3_kernel<2, false>), grid, dim3(NTH), shm, (hipStream_t)stream, dhout, save, whh, dgates, dbias, N, T, H, D);
         CTN_CHECK_LAUNCH("ctn_lstm_bwd");
         return CTN_OK;
     }
     if (H <= 64)
-        hipLaunchKernelGGL(lstm_bwd_kernel<1>, grid, dim3(NTH), 0, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+        hipLaunchKernelGGL(lstm_bwd_kernel<1>, grid, dim3(NTH), 0, (hipStream_t)stream, dhout, save, whh, dgates, dbias, N, T, H, D);
     else
-        hipLaunchKernelGGL(lstm_bwd_kernel<2>, grid, dim3(NTH), 0, (hipStream_t)stream, dhout, save, whh, dgates, N, T, H, D);
+        hipLaunchKernelGGL(lstm_bwd_kernel<2>, grid, dim3(NTH), 0, (hipStream_t)stream, dhout, save, whh, dgates, dbias, N, T, H, D);
     CTN_CHECK_LAUNCH("ctn_lstm_bwd");
     return CTN_OK;
 }

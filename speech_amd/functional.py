@@ -451,11 +451,11 @@ class LstmFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x2, w_ih_all, whh, hout, save, n_dir, (N, T, F_in, H) = ctx.saved
-        dgates = ops.lstm_bwd(dout.contiguous().float().view(N, T, n_dir, H), save, whh)      # (N, T, D, 4H)
+        dgates, db_all = ops.lstm_bwd(dout.contiguous().float().view(N, T, n_dir, H), save, whh)      # (N, T, D, 4H), (D, 4H)
+        db_all = db_all.view(-1)
         dg2 = dgates.view(N * T, n_dir * 4 * H)
         dx = (dg2 @ w_ih_all).view(N, T, F_in) if ctx.needs_input_grad[0] else None
         dw_ih_all = reduce_matmul(dg2, x2)                                # (D*4H, F)
-        db_all = dg2.sum(dim=0)
         # recurrent weights: sum over (n, t) of dgates[n, t]^T h[n, t -+ 1], h of the step before t in the direction's own
         # order.  Over the flat (n, t) index that is one shifted product of the whole tensors, minus the N - 1 terms that
         # pair the first step of a sequence with the last state of its neighbour (no shifted copy of h is made).

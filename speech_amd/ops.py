@@ -280,15 +280,19 @@ def lstm_fwd(xproj, whh):
     return hout, save
 
 
-def lstm_bwd(dhout, save, whh):
-    """dhout (N, T, D, H) -> dgates (N, T, D, 4H) = gradient w.r.t. xproj; see ctn_lstm_bwd."""
+def lstm_bwd(dhout, save, whh, bias_grad=True):
+    """dhout (N, T, D, H) -> dgates (N, T, D, 4H) = gradient w.r.t. xproj, and its sum over (N, T) (D, 4H) = the bias
+    gradient (None if not asked for); see ctn_lstm_bwd."""
     lib = _lib.load()
     _require_cuda(dhout, save, whh)
     N, T, D, H = dhout.shape
     assert dhout.is_contiguous() and save.is_contiguous() and tuple(save.shape) == (N, T, D, 5, H)
+    assert whh.is_contiguous() and tuple(whh.shape) == (D, 4 * H, H)
     dgates = torch.empty((N, T, D, 4 * H), device=dhout.device, dtype=torch.float32)
-    _lib.check(lib.ctn_lstm_bwd(_ptr(dhout), _ptr(save), _ptr(whh), N, T, H, D, _ptr(dgates), _stream()), "ctn_lstm_bwd")
-    return dgates
+    dbias = torch.empty((D, 4 * H), device=dhout.device, dtype=torch.float32) if bias_grad else None
+    _lib.check(lib.ctn_lstm_bwd(_ptr(dhout), _ptr(save), _ptr(whh), N, T, H, D, _ptr(dgates),
+                                _ptr(dbias) if bias_grad else None, _stream()), "ctn_lstm_bwd")
+    return dgates, dbias
 
 
 # ------------------------------------------------------------------------------------------------ axis shuffles

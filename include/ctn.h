@@ -89,6 +89,18 @@ int ctn_sizeof_dw_bwd_args(void);
 #define CTN_ARITH_BF16X2 2
 #define CTN_ARITH_BF16X3 3
 
+/* Which ctn_gemm_nn kernel consumes a prepared A operand (field `prep_kernel`; read only when A_prep is given).  Both
+ * compute the products of CTN_ARITH_BF16X3 in its order: results are bit-identical to each other and to the call
+ * without A_prep.
+ *   CTN_PREP_DEFAULT (0): the same as CTN_PREP_WAVE_SPLIT.
+ *   CTN_PREP_WAVE_SPLIT: the waves of a block sit side by side along time and each splits its own fragment of the fp32
+ *       activation tile in registers; no activation element is split twice in a block, nothing is written back to LDS.
+ *   CTN_PREP_BLOCK_SPLIT: all threads of the block split the activation tile once into fragment order in LDS, one
+ *       k-tile ahead of the matrix instructions (three landing buffers; more LDS, fewer resident blocks). */
+#define CTN_PREP_DEFAULT 0
+#define CTN_PREP_WAVE_SPLIT 1
+#define CTN_PREP_BLOCK_SPLIT 2
+
 /* Measurement aids without a counterpart in the reference: the rates the GPU itself sustains, for the benchmark to
  * report beside the kernels' own.
  * ctn_probe_copy: y = a (b NULL) or y = a + b, n floats (n % 4 == 0, 16-byte aligned), non-temporal 16-byte accesses;
@@ -236,7 +248,7 @@ typedef struct {
     int32_t accumulate;               /* HEADS: Y2 += instead of = */
     int32_t tile_width;               /* output-tile columns of the LDS-DMA kernel: 0 = choose, 64 or 128 */
     int32_t arith;                    /* CTN_ARITH_* */
-    int32_t pad0;
+    int32_t prep_kernel;              /* with A_prep: CTN_PREP_* (which kernel consumes the prepared operand) */
     const float* ealpha;              /* STATS / PRELUBWD / NORMBWD slope (NULL = 1, i.e. no PReLU) */
     double* esums;                    /* [batch][CTN_STAT_SLOTS][2] (+=), PRELUBWD: [CTN_STAT_SLOTS] */
     float* ecol; int64_t ecol_bs, ecol_ld;   /* cLN: [batch][2][ecol_ld] column sums (+=) */

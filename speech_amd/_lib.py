@@ -50,7 +50,7 @@ class GemmNNArgs(C.Structure):
         ("emode", _i32), ("Mo", _i32),
         ("R", _p), ("ldr", _i64), ("rbs", _i64),
         ("Y2", _p), ("ldy2", _i64), ("y2bs", _i64),
-        ("accumulate", _i32), ("tile_width", _i32), ("arith", _i32), ("pad0", _i32),
+        ("accumulate", _i32), ("tile_width", _i32), ("arith", _i32), ("prep_kernel", _i32),
         ("ealpha", _p), ("esums", _p),
         ("ecol", _p), ("ecol_bs", _i64), ("ecol_ld", _i64),
         ("E", _p), ("lde", _i64), ("ebs", _i64),

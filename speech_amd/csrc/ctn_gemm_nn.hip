@@ -406,6 +406,10 @@ constexpr int FBM = 128, FBK = 16;
                        // (-6 % per launch).  The variants with a transform lose with the same request (+6 %).
 #endif
 
+#ifndef CTN_NN_W5
+#define CTN_NN_W5 3      // waves per SIMD of the wave-split prepared variant: its LDS footprint allows three blocks per CU
+#endif
+
 #ifdef CTN_DBG_STAMPS
 // Diagnostic build only: wave 0 of every block records shader-clock stamps of its phases.
 __device__ unsigned long long g_stamps[8192 * 8];
@@ -481,14 +485,22 @@ __device__ __forceinline__ void ctn_lds_store8_untracked(void* p, u32x2 v) {
 // -- one (column, k-group) each -- one k-tile ahead of the MFMAs that consume it.  The MFMA phase then is six 16-byte
 // LDS reads per fragment set and the matrix instructions; products and their order are those of SPLIT = 3, so the
 // results are bit-identical.
+// SPLIT = 5: the same arithmetic again, A prepared as for SPLIT = 4, but the fp32 X tile stays where the DMA put it and
+// each wave transforms and splits ITS fragment in registers.  The waves of a block sit side by side along time (one
+// 128-row x 32-column strip each at the wide tile), so no two waves split the same X element, and the weights -- the
+// operand every wave needs in full -- arrive split: 8 values are split per wave and k-tile where SPLIT = 3 splits 32,
+// with no LDS store and no extra barrier in the loop.
 template <int FBN_, int XF, bool BWD, int SPLIT = 0>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : (SPLIT == 3 && XF == 0 && !BWD ? CTN_NN_W3 : 2)), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : (SPLIT == 3 && XF == 0 && !BWD ? CTN_NN_W3 : (SPLIT == 5 ? CTN_NN_W5 : 2))), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
     // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TILE_A = FBK * FBM, TILE_X = FBK * FBN_;
     constexpr int BUF = TILE_A + TILE_X + (BWD ? TILE_X : 0);
-    constexpr int WN = FBN_ / 2, NJ = WN / 32;            // wave tile 64 x WN = 2 x NJ MFMA tiles
+    constexpr bool PREPW = SPLIT == 5;
+    constexpr bool W14 = PREPW && FBN_ == 128;            // four waves side by side, each over all 128 rows
+    constexpr int WN = PREPW ? 32 : FBN_ / 2, NJ = WN / 32;   // wave tile (32 NI) x WN = NI x NJ MFMA tiles
+    constexpr int NI = W14 ? 4 : 2;
     constexpr int XLPR = FBN_ / 4;                        // lanes per X-tile row in a 1 KiB piece
     constexpr int XRP = 64 / XLPR;                        // X-tile rows per piece
     constexpr int XPW = (FBK / XRP) / 4;                  // X pieces per wave
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
+    const int wm0 = W14 ? 0 : (wave >> 1) * 64, wn0 = W14 ? wave * 32 : (wave & 1) * WN;
     const int M = a.M, T = a.T, K = a.K, K1 = a.K1;
     const float alpha = a.alpha ? a.alpha[0] : 1.f;
     const int nk = (K + FBK - 1) / FBK;
@@ -524,7 +536,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     constexpr int APSZ = 3 * 2 * FBM * 4;                 // PREP: floats of one buffer of A fragments (3 planes x 16 k)
     constexpr int BPSZ = 3 * 2 * FBN_ * 4;                //       ... of X fragments
     constexpr int XLSZ = TILE_X * (BWD ? 2 : 1);          //       ... of one landing buffer (X and, NORMBWD, X2)
-    float* Gs = lds + (PREP ? 2 * APSZ + 2 * BPSZ + 3 * XLSZ : 2 * BUF);
+    constexpr int BUFW = APSZ + XLSZ;                     // PREPW: one buffer = A fragments | X tile | (X2 tile)
+    float* Gs = lds + (PREP ? 2 * APSZ + 2 * BPSZ + 3 * XLSZ : (PREPW ? 2 * BUFW : 2 * BUF));
     float* Bes = Gs + Kp;
     constexpr bool has_norm = BWD || (XF & CTN_XF_NORM) != 0;
     if (has_norm) {
@@ -636,15 +649,102 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     };
 #undef CTN_BLDS16
 
-    f32x16 acc[2][NJ];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (PREP) {
+    if constexpr (PREPW) {
+        const int KG = 2 * nk, Mp = tiles_m * FBM;        // k-groups and padded row count of the prepared matrix
+        const auto rAp = __builtin_amdgcn_make_buffer_rsrc((void*)a.A_prep, 0, 3 * KG * Mp * 16, 0x00020000);
+        const int voAp = lane * 16;
+#define CTN_BLDS16(rs, lp, vo, so) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+        auto issue_w = [&](int kt, int buf) {
+            float* base = lds + buf * BUFW;
+            const int k0 = kt * FBK;
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {             // A fragments: 12 pieces of 1 KiB (plane, k-group, row half)
+                const int q = wv * 3 + pp;
+                const int pl = q >> 2, h = (q >> 1) & 1, mh = q & 1;
+                CTN_BLDS16(rAp, base + q * 256, voAp, ((pl * KG + 2 * kt + h) * Mp + m_blk + mh * 64) * 16);
+            }
+#pragma unroll
+            for (int pp = 0; pp < XPW; ++pp) {           // X tile as it is in memory
+                const int p = wv * XPW + pp;
+                if (k0 < K1)
+                    CTN_BLDS16(rX1, base + APSZ + p * 256, voX1, (k0 + XRP * p) * ldX1 * 4);
+                else
+                    CTN_BLDS16(rXb, base + APSZ + p * 256, voXb, (k0 - K1 + XRP * p) * ldXb * 4);
+                if (BWD) CTN_BLDS16(rX2, base + APSZ + TILE_X + p * 256, voX2, (k0 + XRP * p) * ldX2 * 4);
+            }
+        };
+#undef CTN_BLDS16
+        static_assert(NJ == 1, "wave-split prepared variant: one X fragment per wave");
+        issue_w(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();          // tile kt is complete; buffer (kt+1)&1 is free
+#ifndef CTN_DBG_NO_LOADS
+            if (kt + 1 < nk) issue_w(kt + 1, (kt + 1) & 1);
+#endif
+            const bf16x8* A8 = reinterpret_cast<const bf16x8*>(lds + (kt & 1) * BUFW);
+            const float* Xs = lds + (kt & 1) * BUFW + APSZ;
+            const float* X2s = Xs + TILE_X;
+            const int k0 = kt * FBK;
+            bf16x8 bh, bm, bl;
+            {
+                float bf[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = 8 * half + q;
+                    float v = Xs[k * FBN_ + wn0 + l31];
+                    if (BWD) {
+                        const float y = X2s[k * FBN_ + wn0 + l31];
+                        const float sl = y > 0.f ? 1.f : alpha;
+                        v = sl * __builtin_fmaf(Gs[k0 + k] * v, rstd[0], __builtin_fmaf(sl * y, c2[0], c1m[0]));
+                    }
+                    if (XF & CTN_XF_PRELU) v = ctn_prelu_med(v, alpha, plim);
+                    if (XF & CTN_XF_NORM) v = __builtin_fmaf(__builtin_fmaf(v, rstd[0], nmr[0]), Gs[k0 + k], Bes[k0 + k]);
+                    bf[q] = v;
+                }
+#ifdef CTN_DBG_W_NOSPLIT              // (timing builds: results are wrong)
+                union { bf16x8 v; float f[4]; } raw;
+                raw.f[0] = bf[0] + bf[4], raw.f[1] = bf[1] + bf[5], raw.f[2] = bf[2] + bf[6], raw.f[3] = bf[3] + bf[7];
+                bh = bm = bl = raw.v;
+#else
+                ctn_split_bf16_3(bf, bh, bm, bl);
+#endif
+            }
+#pragma unroll
+            for (int ip = 0; ip < NI; ip += 2) {          // two row tiles at a time: their MFMAs alternate
+                bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int ix = half * FBM + wm0 + (ip + ii) * 32 + l31;
+#ifdef CTN_DBG_W_NOAREAD             // (timing builds: results are wrong)
+                    ah[ii] = am[ii] = al[ii] = bh;
+                    if (ix == 1 << 30) ah[ii] = A8[ix];
+#else
+                    ah[ii] = A8[ix], am[ii] = A8[2 * FBM + ix], al[ii] = A8[4 * FBM + ix];
+#endif
+                }
+#define CTN_NN_MFMA(a_, b_)                                                                                             \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                    \
+        acc[ip + ii][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[ii], b_, acc[ip + ii][0], 0, 0, 0)
+                CTN_NN_MFMA(al, bh);
+                CTN_NN_MFMA(ah, bl);
+                CTN_NN_MFMA(am, bm);
+                CTN_NN_MFMA(am, bh);
+                CTN_NN_MFMA(ah, bm);
+                CTN_NN_MFMA(ah, bh);
+#undef CTN_NN_MFMA
+            }
+        }
+    } else if constexpr (PREP) {
         float* const APb = lds;
         float* const BPb = lds + 2 * APSZ;
         float* const XLb = BPb + 2 * BPSZ;
@@ -905,7 +1005,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     {
         float keep = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -916,6 +1016,19 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
 #endif
 
     // ------------------------------------------------------------------ epilogue through LDS
+    // The barriers between staging and storing order LDS traffic only.  __syncthreads() also waits for every global
+    // store of the wave to be acknowledged (its fence covers global memory), which would put one full write latency
+    // between the two passes of every block; the stores of pass 0 stay in flight across these barriers instead.
+#ifdef CTN_DBG_EPI_FULL_BARRIER
+#define CTN_LDS_BARRIER() __syncthreads()
+#else
+#define CTN_LDS_BARRIER()                                   \
+    do {                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                       \
+        asm volatile("" ::: "memory");                      \
+    } while (0)
+#endif
     float* stg = lds;             // 64 x FBN_ floats <= 2 * BUF
     constexpr int TPR = FBN_ / 4;                 // threads per staged row
     constexpr int RS = NTH / TPR;                 // rows per sweep of the block
@@ -966,13 +1079,21 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     for (int pass = 0; pass < 2; ++pass) {
         // every wave stages its MFMA row tile `pass` (staging rows 0..31: tile rows 32 pass .. of the upper wave
         // pair, 32..63: of the lower pair), so half of each wave's accumulators are dead from here on
+        if constexpr (W14) {      // side-by-side waves: row tiles 2 pass and 2 pass + 1 of every wave's strip
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stg[((wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + j * 32 + l31] = acc[pass][j][r];
-        __syncthreads();
-        auto tile_row = [&](int srow) { return (srow >> 5) * 64 + pass * 32 + (srow & 31); };
+                for (int r = 0; r < 16; ++r)
+                    stg[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + l31] = acc[pass * 2 + ii][0][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stg[((wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + j * 32 + l31] = acc[pass][j][r];
+        }
+        CTN_LDS_BARRIER();
+        auto tile_row = [&](int srow) { return W14 ? pass * 64 + srow : (srow >> 5) * 64 + pass * 32 + (srow & 31); };
         f32x4 aux[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) aux[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1035,7 +1156,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
             }
             if (ok) ctn_st4(op, v);
         }
-        __syncthreads();
+        CTN_LDS_BARRIER();
     }
     if (want_stats) {
         if (a.ecol) {            // per-frame sums: fold the RS row groups through LDS, one atomic per frame
@@ -1216,7 +1337,17 @@ size_t prep_lds_bytes(const ctn_gemm_nn_args& a, int width) {
     return floats * sizeof(float);
 }
 
-template <int FBN_, int XF, bool BWD>
+// Wave-split prepared variant.  LDS: two buffers of (A fragments | X tile | X2 tile with the norm-backward operand), the
+// gamma / beta rows, and at least the epilogue's staging area.
+size_t prepw_lds_bytes(const ctn_gemm_nn_args& a, int width) {
+    const int Kp = ctn_cdiv(a.K, FBK) * FBK;
+    const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
+    size_t floats = 2 * ((size_t)(3 * 2 * FBM * 4) + (size_t)(FBK * width) * (bwd ? 2 : 1)) + (bwd ? 1 : 2) * (size_t)Kp;
+    if (floats < (size_t)64 * width) floats = (size_t)64 * width;
+    return floats * sizeof(float);
+}
+
+template <int FBN_, int XF, bool BWD, int SP = 4>
 int launch_prep_k(const ctn_gemm_nn_args& a, hipStream_t s) {
     const int tiles_m = ctn_cdiv(a.M, FBM), tiles_n = ctn_cdiv(a.T, FBN_);
     const int64_t total = (int64_t)tiles_m * tiles_n * a.batch;
@@ -1224,8 +1355,8 @@ int launch_prep_k(const ctn_gemm_nn_args& a, hipStream_t s) {
         ctn_set_error("ctn_gemm_nn: grid too large");
         return CTN_ERR_ARG;
     }
-    const size_t shmem = prep_lds_bytes(a, FBN_);
-    auto kern = gemm_nn_fast_kernel<FBN_, XF, BWD, 4>;
+    const size_t shmem = SP == 5 ? prepw_lds_bytes(a, FBN_) : prep_lds_bytes(a, FBN_);
+    auto kern = gemm_nn_fast_kernel<FBN_, XF, BWD, SP>;
     if (shmem > 48 * 1024) {      // more dynamic LDS than a kernel gets by default: ask once per device
         static bool asked[64] = {};
         int dev = 0;
@@ -1243,23 +1374,26 @@ int launch_prep_k(const ctn_gemm_nn_args& a, hipStream_t s) {
     return CTN_OK;
 }
 
-template <int FBN_>
+template <int FBN_, int SP>
 int launch_prep_n(const ctn_gemm_nn_args& a, hipStream_t s) {
-    if (a.xflags & CTN_XF_NORMBWD) return launch_prep_k<FBN_, 0, true>(a, s);
+    if (a.xflags & CTN_XF_NORMBWD) return launch_prep_k<FBN_, 0, true, SP>(a, s);
     switch (a.xflags & (CTN_XF_PRELU | CTN_XF_NORM)) {
-        case 0: return launch_prep_k<FBN_, 0, false>(a, s);
-        case CTN_XF_PRELU: return launch_prep_k<FBN_, CTN_XF_PRELU, false>(a, s);
-        case CTN_XF_NORM: return launch_prep_k<FBN_, CTN_XF_NORM, false>(a, s);
-        default: return launch_prep_k<FBN_, CTN_XF_PRELU | CTN_XF_NORM, false>(a, s);
+        case 0: return launch_prep_k<FBN_, 0, false, SP>(a, s);
+        case CTN_XF_PRELU: return launch_prep_k<FBN_, CTN_XF_PRELU, false, SP>(a, s);
+        case CTN_XF_NORM: return launch_prep_k<FBN_, CTN_XF_NORM, false, SP>(a, s);
+        default: return launch_prep_k<FBN_, CTN_XF_PRELU | CTN_XF_NORM, false, SP>(a, s);
     }
 }
 
-// Tile width of the prepared-A variant: the caller's, else 128 columns -- except with the norm-backward operand, whose
-// second landing tile would leave room for one block per CU only at that width.
+// Tile width of the prepared-A variants: the caller's, else 128 columns (measured on the wave-split kernel with the
+// norm-backward operand: 132 us at 128 columns and two blocks per CU, 149 us at 64 columns and three).
 int launch_prep(const ctn_gemm_nn_args& a, hipStream_t s) {
-    const int width = (a.tile_width == 64 || a.tile_width == 128) ? a.tile_width
-                                                                  : ((a.xflags & CTN_XF_NORMBWD) ? 64 : 128);
-    return width == 128 ? launch_prep_n<128>(a, s) : launch_prep_n<64>(a, s);
+    // block-split kernel: the second landing tile of the norm-backward operand leaves room for one block per CU at 128
+    const bool narrow = (a.xflags & CTN_XF_NORMBWD) && a.prep_kernel == CTN_PREP_BLOCK_SPLIT;
+    const int width = (a.tile_width == 64 || a.tile_width == 128) ? a.tile_width : (narrow ? 64 : 128);
+    if (a.prep_kernel == CTN_PREP_BLOCK_SPLIT)
+        return width == 128 ? launch_prep_n<128, 4>(a, s) : launch_prep_n<64, 4>(a, s);
+    return width == 128 ? launch_prep_n<128, 5>(a, s) : launch_prep_n<64, 5>(a, s);
 }
 
 int launch_fast(const ctn_gemm_nn_args& a, hipStream_t s) {
@@ -1291,6 +1425,8 @@ extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
     CTN_REQUIRE(a.M > 0 && a.T > 0 && a.K > 0 && a.batch > 0, "ctn_gemm_nn: empty problem");
     CTN_REQUIRE(a.arith >= CTN_ARITH_DEFAULT && a.arith <= CTN_ARITH_BF16X3, "ctn_gemm_nn: arith is one of CTN_ARITH_*");
     CTN_REQUIRE(a.tile_width == 0 || a.tile_width == 64 || a.tile_width == 128, "ctn_gemm_nn: tile_width is 0, 64 or 128");
+    CTN_REQUIRE(a.prep_kernel >= CTN_PREP_DEFAULT && a.prep_kernel <= CTN_PREP_BLOCK_SPLIT,
+                "ctn_gemm_nn: prep_kernel is one of CTN_PREP_*");
     CTN_REQUIRE((a.A || a.A_prep) && a.X && a.Y, "ctn_gemm_nn: null A / X / Y");
     CTN_REQUIRE(a.K1 >= 0 && a.K1 <= a.K, "ctn_gemm_nn: K1 out of range");
     CTN_REQUIRE(a.K1 == a.K || ((a.A2 || a.A_prep) && a.Xb), "ctn_gemm_nn: split K needs A2 and Xb");

@@ -29,10 +29,11 @@ RECOMPUTE_DW_OUTPUT = os.environ.get("CTN_DW_RECOMPUTE", "1") != "0"
 
 # In the default arithmetic (three bf16 pieces) the weight operand of every pointwise GEMM can be split once per step
 # into the matrix instruction's own layout (ops.prepared / PreparedWeights) instead of by every wave that reads it; the
-# results are bit-identical and a pass has 70 launches fewer (no weight transposes).  Off by default: at the benchmark's
-# batch the prepared-operand kernel, which holds two blocks per CU where the in-kernel split holds three, is 8 % slower
-# on the 512-row shapes.  CTN_PREPARED_WEIGHTS=1 switches it on.
-USE_PREPARED_WEIGHTS = os.environ.get("CTN_PREPARED_WEIGHTS", "0") != "0"
+# results are bit-identical.  On by default: with the weights arriving split, the waves of a GEMM block sit side by
+# side along time and each splits only its own activation fragment (a quarter of the vector work of the in-kernel
+# split), which is 4-5 % of a training step at the benchmark's batch.  CTN_PREPARED_WEIGHTS=0 restores the in-kernel
+# split of both operands.
+USE_PREPARED_WEIGHTS = os.environ.get("CTN_PREPARED_WEIGHTS", "1") != "0"
 
 FLAT_ALIGN = 64      # floats: every tensor of a flat parameter / gradient buffer starts on a 256-byte boundary
 

@@ -207,6 +207,7 @@ def _initial_split():
 
 _gemm_split = _initial_split()
 _gemm_tile = 0
+_prep_kernel = int(os.environ.get("CTN_PREP_KERNEL", "0"))      # CTN_PREP_* for calls that do not say (diagnostics)
 
 
 def set_gemm_split(pieces):
@@ -499,9 +500,10 @@ def norm_bwd_apply(dn, x, alpha, stat, gamma, dx, dalpha):
 def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, xflags=0, X2=None, alpha=None,
             stat=None, gamma=None, beta=None, bias=None, bias2=None, emode=EPI_STORE, Mo=0, R=None, Y2=None,
             accumulate=False, ealpha=None, eacc=None, E=None, estat=None, egamma=None, esums=None, tile_width=0,
-            A_prep=None, fin=None):
+            A_prep=None, fin=None, prep_kernel=0):
     """Y[b] = A(k-major) . xform(X[b]); see ctn_gemm_nn in include/ctn.h.  X/Xb/X2/Y/Y2/R/E are act views.  A_prep: the
-    same A as a prepared matrix (prepared() / weight_prep()); A, A2 may then be None."""
+    same A as a prepared matrix (prepared() / weight_prep()); A, A2 may then be None.  prep_kernel: CTN_PREP_* (0 = the
+    library's choice, 1 = wave-split, 2 = block-split kernel for the prepared operand)."""
     lib = _lib.load()
     a = _lib.GemmNNArgs()
     a.tile_width = tile_width or _gemm_tile
@@ -541,6 +543,7 @@ def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, 
         a.emean, a.erstd, a.essb, a.esst = _ptr(estat.mean), _ptr(estat.rstd), estat.sb, estat.st
     a.egamma = _ptr(egamma)
     a.A_prep = _ptr(A_prep)
+    a.prep_kernel = prep_kernel or _prep_kernel
     _set_fin(a.fin, fin)
     _lib.check(lib.ctn_gemm_nn(C.byref(a), _stream()), "ctn_gemm_nn")
 

@@ -15,6 +15,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[1, 2], ids=["wave_split", "block_split"], autouse=True)
+def prep_kernel(request):
+    """Every test runs once per kernel that consumes the prepared operand (CTN_PREP_WAVE_SPLIT, CTN_PREP_BLOCK_SPLIT)."""
+    from speech_amd import ops
+    before = ops._prep_kernel
+    ops._prep_kernel = request.param
+    yield request.param
+    ops._prep_kernel = before
+
+
 def rnd(shape, seed, scale=1.0):
     return synth.normal(shape, seed).double() * scale
 

@@ -666,12 +666,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
         auto issue_w = [&](int kt, int buf) {
             float* base = lds + buf * BUFW;
             const int k0 = kt * FBK;
+#ifndef CTN_DBG_W_NO_ALOADS           // (timing builds: results are wrong)
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) {             // A fragments: 12 pieces of 1 KiB (plane, k-group, row half)
                 const int q = wv * 3 + pp;
                 const int pl = q >> 2, h = (q >> 1) & 1, mh = q & 1;
                 CTN_BLDS16(rAp, base + q * 256, voAp, ((pl * KG + 2 * kt + h) * Mp + m_blk + mh * 64) * 16);
             }
+#endif
+#ifndef CTN_DBG_W_NO_XLOADS
 #pragma unroll
             for (int pp = 0; pp < XPW; ++pp) {           // X tile as it is in memory
                 const int p = wv * XPW + pp;
@@ -681,6 +684,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
                     CTN_BLDS16(rXb, base + APSZ + p * 256, voXb, (k0 - K1 + XRP * p) * ldXb * 4);
                 if (BWD) CTN_BLDS16(rX2, base + APSZ + TILE_X + p * 256, voX2, (k0 + XRP * p) * ldX2 * 4);
             }
+#endif
         };
 #undef CTN_BLDS16
         static_assert(NJ == 1, "wave-split prepared variant: one X fragment per wave");

@@ -368,7 +368,7 @@ def main():
             trainer.n_streams = keep_streams
         recipe = dict(value=round(2 * n_small / dt2, 3), unit="utt/s", per_gpu_batch=2, steps=n_small,
                       ms_per_step=round(dt2 / n_small * 1e3, 3),
-                      note="the reference recipe's batch size per GPU; a step is ~570 launches that no longer fill the chip")
+                      note="the reference recipe's batch size per GPU; a step is ~300 launches that no longer fill the chip")
 
     roof = roof_hbm = None
     extra = {}

@@ -250,6 +250,9 @@ void launch(const ctn_gemm_nt_args& a, hipStream_t s) {
 
 // CLN: the statistics are rows over frames (cumulative norm) instead of one value per batch element; every use
 // fetches the four frames of its group with one 16-byte load from a row that stays in L2.
+#ifndef CTN_NT_WKS
+#define CTN_NT_WKS 3     // waves per SIMD asked for the frame-divided variant (its LDS footprint allows three blocks per CU)
+#endif
 typedef __bf16 ntbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 ntbf16x2 __attribute__((ext_vector_type(2)));
 typedef float ntf32x2 __attribute__((ext_vector_type(2)));
@@ -285,13 +288,18 @@ __device__ __forceinline__ void nt_split_bf16_3(const float (&x)[8], ntbf16x8& h
 // SPLIT = 2: products on the bf16 MFMA from operands split into two bf16 pieces (hi*hi + hi*lo + lo*hi, fp32
 // accumulation), one instruction triple per 16 frames instead of eight f32 MFMAs; SPLIT = 3: three pieces and the six
 // leading products (all 24 mantissa bits).  See CTN_ARITH_* in include/ctn.h.
-template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN, int SPLIT = 0>
-__global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_args a, const int tiles_m,
-                                                           const int tiles_n, const int nchunks) {
+// KS (split modes, 32-frame k-tiles): the two waves of a tile row share its COLUMNS and divide the k-tile's FRAMES
+// between them (wave pair member 0 the first 16 frames, member 1 the last 16) instead of dividing the columns.  Each A
+// fragment is then split by one wave instead of two -- 32 values per wave and 24 matrix instructions where the
+// column-divided form splits 48 -- and both waves add their partial tiles to C, which is an atomic target anyway.
+template <int TM, int TN, int FK, bool BWD, int BXF, bool CLN, int SPLIT = 0, bool KS = false>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT_WKS : 1, 8))) void gemm_nt_fast_kernel(
+    const ctn_gemm_nt_args a, const int tiles_m, const int tiles_n, const int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(!KS || (SPLIT != 0 && FK == 32 && !BWD), "frame-divided wave pairs: split modes, 32-frame k-tiles");
     constexpr int FTA = TM * FK, FTB = TN * FK;           // floats per operand tile
     constexpr int BUF = FTA + FTB + (BWD ? FTA : 0);     // A | B | (A2)
-    constexpr int WTM = TM / 2, WTN = TN / 2;             // wave tile WTM x WTN
+    constexpr int WTM = TM / 2, WTN = KS ? TN : TN / 2;   // wave tile WTM x WTN
     constexpr int TTM = WTM / 32, TTN = WTN / 32;         // MFMA tiles per wave
     constexpr int SPR = FK / 4;                           // 16-byte slots (frame groups) per tile row
     constexpr int RPP = 64 / SPR;                         // rows per 1 KiB DMA piece
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * WTM, wn0 = (wave & 1) * WTN;
+    const int wm0 = (wave >> 1) * WTM, wn0 = KS ? 0 : (wave & 1) * WTN;
 
     constexpr int RS_BYTES = 0x40000000;
     const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A ? a.A + (int64_t)b * a.abs_ : a.Ab), 0, RS_BYTES,
@@ -425,7 +433,8 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         }
     };
     // the two waves of a tile row read the same A rows: one of them reduces, and only in the first tile column
-    const bool reducer = (tile_n == 0) && ((wave & 1) == 0);
+    // (frame-divided pairs read different frames of those rows: both reduce)
+    const bool reducer = (tile_n == 0) && (KS || (wave & 1) == 0);
     const bool do_rowsum = reducer && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr);
     float rowsum[TTM];
 #pragma unroll
@@ -448,7 +457,8 @@ __global__ __launch_bounds__(NTH) void gemm_nt_fast_kernel(const ctn_gemm_nt_arg
         const float* Bs = As + FTA;
         if constexpr (SPLIT != 0) {
 #pragma unroll
-            for (int c2 = 0; c2 < FK / 16; ++c2) {        // 16 frames per bf16 MFMA: this half-wave's two frame groups
+            for (int c2i = 0; c2i < (KS ? 1 : FK / 16); ++c2i) {   // 16 frames per bf16 MFMA: this half-wave's two frame groups
+                const int c2 = KS ? (wave & 1) : c2i;
                 float a8[TTM][8], b8[TTN][8];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -778,7 +788,7 @@ bool stat_rows(const ctn_gemm_nt_args& a) {
     return ((a.aflags & CTN_XF_NORMBWD) && a.a_sst == 1) || ((a.bflags & CTN_XF_NORM) && a.b_sst == 1);
 }
 
-template <int TM, int TN, bool BWD, int BXF, int FK = (BWD ? 16 : 32)>
+template <int TM, int TN, bool BWD, int BXF, int FK = (BWD ? 16 : 32), bool KS = false>
 void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const int tiles_m = ctn_cdiv(a.M, TM), tiles_n = ctn_cdiv(a.N, TN);
     const int nchunks = ctn_cdiv(a.T, a.kchunk);
@@ -788,8 +798,8 @@ void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const int split = a.arith == CTN_ARITH_F32 ? 0 : (a.arith == CTN_ARITH_BF16X2 ? 2 : 3);
     const bool rows = stat_rows(a);
 #define CTN_NT_LAUNCH(CLN_, SP)                                                                                        \
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, CLN_, SP>), dim3(total), dim3(NTH), shmem, s, a,     \
-                       tiles_m, tiles_n, nchunks)
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<TM, TN, FK, BWD, BXF, CLN_, SP, (KS && SP != 0)>), dim3(total), dim3(NTH), \
+                       shmem, s, a, tiles_m, tiles_n, nchunks)
     if (rows) {
         if (split == 3) CTN_NT_LAUNCH(true, 3);
         else if (split == 2) CTN_NT_LAUNCH(true, 2);
@@ -817,10 +827,15 @@ void launch_fast(const ctn_gemm_nt_args& a, hipStream_t s) {
             else launch_fast_x<64, 64, true, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
         }
     } else if (tall_m(a)) {
-        if (bxf == 0) launch_fast_x<128, 64, false, 0>(a, s);
-        else if (bxf == CTN_XF_PRELU) launch_fast_x<128, 64, false, CTN_XF_PRELU>(a, s);
-        else if (bxf == CTN_XF_NORM) launch_fast_x<128, 64, false, CTN_XF_NORM>(a, s);
-        else launch_fast_x<128, 64, false, CTN_XF_PRELU | CTN_XF_NORM>(a, s);
+#ifdef CTN_DBG_NT_NO_KS
+        constexpr bool ks = false;
+#else
+        constexpr bool ks = true;
+#endif
+        if (bxf == 0) launch_fast_x<128, 64, false, 0, 32, ks>(a, s);
+        else if (bxf == CTN_XF_PRELU) launch_fast_x<128, 64, false, CTN_XF_PRELU, 32, ks>(a, s);
+        else if (bxf == CTN_XF_NORM) launch_fast_x<128, 64, false, CTN_XF_NORM, 32, ks>(a, s);
+        else launch_fast_x<128, 64, false, CTN_XF_PRELU | CTN_XF_NORM, 32, ks>(a, s);
     } else {
         if (bxf == 0) launch_fast_x<64, 64, false, 0>(a, s);
         else if (bxf == CTN_XF_PRELU) launch_fast_x<64, 64, false, CTN_XF_PRELU>(a, s);

@@ -92,14 +92,17 @@ int ctn_sizeof_dw_bwd_args(void);
 /* Which ctn_gemm_nn kernel consumes a prepared A operand (field `prep_kernel`; read only when A_prep is given).  Both
  * compute the products of CTN_ARITH_BF16X3 in its order: results are bit-identical to each other and to the call
  * without A_prep.
- *   CTN_PREP_DEFAULT (0): the same as CTN_PREP_WAVE_SPLIT.
- *   CTN_PREP_WAVE_SPLIT: the waves of a block sit side by side along time and each splits its own fragment of the fp32
- *       activation tile in registers; no activation element is split twice in a block, nothing is written back to LDS.
+ *   CTN_PREP_DEFAULT (0): CTN_PREP_WAVE_SPLIT8 unless the call names a tile_width or carries the norm-backward operand
+ *       transform (then CTN_PREP_WAVE_SPLIT).
+ *   CTN_PREP_WAVE_SPLIT: the four waves of a block sit side by side along time and each splits its own fragment of the
+ *       fp32 activation tile in registers; no activation element is split twice in a block, nothing is written back to LDS.
  *   CTN_PREP_BLOCK_SPLIT: all threads of the block split the activation tile once into fragment order in LDS, one
  *       k-tile ahead of the matrix instructions (three landing buffers; more LDS, fewer resident blocks). */
 #define CTN_PREP_DEFAULT 0
 #define CTN_PREP_WAVE_SPLIT 1
 #define CTN_PREP_BLOCK_SPLIT 2
+/*   CTN_PREP_WAVE_SPLIT8: the wave-split kernel with eight waves over a 128 x 256 tile (tile_width is not read). */
+#define CTN_PREP_WAVE_SPLIT8 3
 
 /* Measurement aids without a counterpart in the reference: the rates the GPU itself sustains, for the benchmark to
  * report beside the kernels' own.

@@ -490,21 +490,28 @@ __device__ __forceinline__ void ctn_lds_store8_untracked(void* p, u32x2 v) {
 // 128-row x 32-column strip each at the wide tile), so no two waves split the same X element, and the weights -- the
 // operand every wave needs in full -- arrive split: 8 values are split per wave and k-tile where SPLIT = 3 splits 32,
 // with no LDS store and no extra barrier in the loop.
+// SPLIT = 6: SPLIT = 5 with EIGHT waves side by side (512 threads, FBN_ = 256 columns): one set of A fragments per k-tile
+// serves twice the matrix instructions, and two blocks of 56 KB put 16 waves on a CU where three of the four-wave blocks
+// put 12; a launch of the training step's shapes is then a whole number of generations of the chip's 512 block slots.
 template <int FBN_, int XF, bool BWD, int SPLIT = 0>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : (SPLIT == 3 && XF == 0 && !BWD ? CTN_NN_W3 : (SPLIT == 5 ? CTN_NN_W5 : 2))), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
+__global__ __launch_bounds__(SPLIT == 6 ? 2 * NTH : NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 ? 4 : (SPLIT == 2 ? 3 : (SPLIT == 3 && XF == 0 && !BWD ? CTN_NN_W3 : (SPLIT == 5 ? CTN_NN_W5 : (SPLIT == 6 ? 4 : 2)))), 4))) void gemm_nn_fast_kernel(const ctn_gemm_nn_args a, const int tiles_m,
                                                            const int tiles_n) {
+    constexpr int NTHB = SPLIT == 6 ? 2 * NTH : NTH;      // threads of a block
+    constexpr int NWV = NTHB / 64;
+    static_assert(SPLIT != 6 || FBN_ == 256, "eight-wave variant: 256 columns");
+    static_assert(SPLIT == 6 || FBN_ <= 128, "four-wave variants: 64 or 128 columns");
     // LDS: [2 buffers][A tile | X tile | (X2 tile)] | gamma[Kp] | beta[Kp];  epilogue staging aliases the tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TILE_A = FBK * FBM, TILE_X = FBK * FBN_;
     constexpr int BUF = TILE_A + TILE_X + (BWD ? TILE_X : 0);
-    constexpr bool PREPW = SPLIT == 5;
-    constexpr bool W14 = PREPW && FBN_ == 128;            // four waves side by side, each over all 128 rows
+    constexpr bool PREPW = SPLIT == 5 || SPLIT == 6;
+    constexpr bool W14 = PREPW && FBN_ >= 128;            // the waves side by side, each over all 128 rows
     constexpr int WN = PREPW ? 32 : FBN_ / 2, NJ = WN / 32;   // wave tile (32 NI) x WN = NI x NJ MFMA tiles
     constexpr int NI = W14 ? 4 : 2;
     constexpr int XLPR = FBN_ / 4;                        // lanes per X-tile row in a 1 KiB piece
     constexpr int XRP = 64 / XLPR;                        // X-tile rows per piece
-    constexpr int XPW = (FBK / XRP) / 4;                  // X pieces per wave
-    __shared__ float red[2 * (NTH / 64)];
+    constexpr int XPW = (FBK / XRP) / NWV;                // X pieces per wave
+    __shared__ float red[2 * NWV];
     __shared__ float rowc[2][FBM];
 
     CTN_STAMP(0);
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     float* Bes = Gs + Kp;
     constexpr bool has_norm = BWD || (XF & CTN_XF_NORM) != 0;
     if (has_norm) {
-        for (int k = tid; k < Kp; k += NTH) {
+        for (int k = tid; k < Kp; k += NTHB) {
             Gs[k] = k < K ? a.gamma[k] : 0.f;
             if (!BWD) Bes[k] = k < K ? a.beta[k] : 0.f;      // (the norm-backward variant has no beta row)
         }
@@ -667,11 +674,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
             float* base = lds + buf * BUFW;
             const int k0 = kt * FBK;
 #ifndef CTN_DBG_W_NO_ALOADS           // (timing builds: results are wrong)
+            if (NWV == 4 || wv < 4) {                    // (uniform) eight waves: the first four fetch the A fragments
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) {             // A fragments: 12 pieces of 1 KiB (plane, k-group, row half)
-                const int q = wv * 3 + pp;
-                const int pl = q >> 2, h = (q >> 1) & 1, mh = q & 1;
-                CTN_BLDS16(rAp, base + q * 256, voAp, ((pl * KG + 2 * kt + h) * Mp + m_blk + mh * 64) * 16);
+                for (int pp = 0; pp < 3; ++pp) {         // A fragments: 12 pieces of 1 KiB (plane, k-group, row half)
+                    const int q = wv * 3 + pp;
+                    const int pl = q >> 2, h = (q >> 1) & 1, mh = q & 1;
+                    CTN_BLDS16(rAp, base + q * 256, voAp, ((pl * KG + 2 * kt + h) * Mp + m_blk + mh * 64) * 16);
+                }
             }
 #endif
 #ifndef CTN_DBG_W_NO_XLOADS
@@ -1035,7 +1044,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
 #endif
     float* stg = lds;             // 64 x FBN_ floats <= 2 * BUF
     constexpr int TPR = FBN_ / 4;                 // threads per staged row
-    constexpr int RS = NTH / TPR;                 // rows per sweep of the block
+    constexpr int RS = NTHB / TPR;                // rows per sweep of the block
+    constexpr int PROWS = SPLIT == 6 ? 32 : 64;   // tile rows staged per pass
+    constexpr int NPASS = FBM / PROWS;
     const int emode = a.emode;
     const float ea = a.ealpha ? a.ealpha[0] : 1.f;
     const int c4 = (tid % TPR) * 4, r0 = tid / TPR;        // this thread: columns c4..c4+3, rows r0 + RS q
@@ -1056,7 +1067,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
     // Row constants come from LDS (rowc, filled in the prologue) and the optional per-element input (residual,
     // accumulate target or pre-activation) is fetched 4 rows ahead with unconditional loads: a load inside the
     // row loop would put a full vmcnt wait -- which also waits for the stores before it -- in front of every store.
-    constexpr int NQ = 64 / RS;
+    constexpr int NQ = PROWS / RS;
     const int split = (emode == CTN_EPI_HEADS) ? a.Mo : M;          // rows >= split go to Y2
     const float* lo_base = a.Y; int64_t lo_ld = a.ldy, lo_bs = a.ybs; bool lo_use = false;
     const float* hi_base = a.Y; int64_t hi_ld = a.ldy, hi_bs = a.ybs; bool hi_use = false;
@@ -1080,10 +1091,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
         return hi_base + (int64_t)b * hi_bs + (int64_t)(mc - split) * hi_ld + tl;
     };
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         // every wave stages its MFMA row tile `pass` (staging rows 0..31: tile rows 32 pass .. of the upper wave
         // pair, 32..63: of the lower pair), so half of each wave's accumulators are dead from here on
-        if constexpr (W14) {      // side-by-side waves: row tiles 2 pass and 2 pass + 1 of every wave's strip
+        if constexpr (SPLIT == 6) {   // eight waves side by side: row tile `pass` of every wave's strip
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + l31] = acc[pass][0][r];
+        } else if constexpr (W14) {      // side-by-side waves: row tiles 2 pass and 2 pass + 1 of every wave's strip
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -1097,7 +1112,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(SPLIT == 0 
                     stg[((wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FBN_ + wn0 + j * 32 + l31] = acc[pass][j][r];
         }
         CTN_LDS_BARRIER();
-        auto tile_row = [&](int srow) { return W14 ? pass * 64 + srow : (srow >> 5) * 64 + pass * 32 + (srow & 31); };
+        auto tile_row = [&](int srow) { return W14 ? pass * PROWS + srow : (srow >> 5) * 64 + pass * 32 + (srow & 31); };
         f32x4 aux[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) aux[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1347,7 +1362,8 @@ size_t prepw_lds_bytes(const ctn_gemm_nn_args& a, int width) {
     const int Kp = ctn_cdiv(a.K, FBK) * FBK;
     const bool bwd = (a.xflags & CTN_XF_NORMBWD) != 0;
     size_t floats = 2 * ((size_t)(3 * 2 * FBM * 4) + (size_t)(FBK * width) * (bwd ? 2 : 1)) + (bwd ? 1 : 2) * (size_t)Kp;
-    if (floats < (size_t)64 * width) floats = (size_t)64 * width;
+    const size_t staging = (size_t)(width == 256 ? 32 : 64) * width;
+    if (floats < staging) floats = staging;
     return floats * sizeof(float);
 }
 
@@ -1359,7 +1375,7 @@ int launch_prep_k(const ctn_gemm_nn_args& a, hipStream_t s) {
         ctn_set_error("ctn_gemm_nn: grid too large");
         return CTN_ERR_ARG;
     }
-    const size_t shmem = SP == 5 ? prepw_lds_bytes(a, FBN_) : prep_lds_bytes(a, FBN_);
+    const size_t shmem = SP >= 5 ? prepw_lds_bytes(a, FBN_) : prep_lds_bytes(a, FBN_);
     auto kern = gemm_nn_fast_kernel<FBN_, XF, BWD, SP>;
     if (shmem > 48 * 1024) {      // more dynamic LDS than a kernel gets by default: ask once per device
         static bool asked[64] = {};
@@ -1374,7 +1390,7 @@ int launch_prep_k(const ctn_gemm_nn_args& a, hipStream_t s) {
             asked[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NTH), shmem, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(SP == 6 ? 2 * NTH : NTH), shmem, s, a, tiles_m, tiles_n);
     return CTN_OK;
 }
 
@@ -1397,6 +1413,11 @@ int launch_prep(const ctn_gemm_nn_args& a, hipStream_t s) {
     const int width = (a.tile_width == 64 || a.tile_width == 128) ? a.tile_width : (narrow ? 64 : 128);
     if (a.prep_kernel == CTN_PREP_BLOCK_SPLIT)
         return width == 128 ? launch_prep_n<128, 4>(a, s) : launch_prep_n<64, 4>(a, s);
+    // eight waves over 256 columns unless the caller names a width or a kernel; not with the norm-backward operand,
+    // whose second X tile would leave room for one such block per CU
+    const bool wide8 = a.prep_kernel == CTN_PREP_WAVE_SPLIT8 ||
+                       (a.prep_kernel == CTN_PREP_DEFAULT && a.tile_width == 0 && !(a.xflags & CTN_XF_NORMBWD));
+    if (wide8) return launch_prep_n<256, 6>(a, s);
     return width == 128 ? launch_prep_n<128, 5>(a, s) : launch_prep_n<64, 5>(a, s);
 }
 
@@ -1429,7 +1450,7 @@ extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
     CTN_REQUIRE(a.M > 0 && a.T > 0 && a.K > 0 && a.batch > 0, "ctn_gemm_nn: empty problem");
     CTN_REQUIRE(a.arith >= CTN_ARITH_DEFAULT && a.arith <= CTN_ARITH_BF16X3, "ctn_gemm_nn: arith is one of CTN_ARITH_*");
     CTN_REQUIRE(a.tile_width == 0 || a.tile_width == 64 || a.tile_width == 128, "ctn_gemm_nn: tile_width is 0, 64 or 128");
-    CTN_REQUIRE(a.prep_kernel >= CTN_PREP_DEFAULT && a.prep_kernel <= CTN_PREP_BLOCK_SPLIT,
+    CTN_REQUIRE(a.prep_kernel >= CTN_PREP_DEFAULT && a.prep_kernel <= CTN_PREP_WAVE_SPLIT8,
                 "ctn_gemm_nn: prep_kernel is one of CTN_PREP_*");
     CTN_REQUIRE((a.A || a.A_prep) && a.X && a.Y, "ctn_gemm_nn: null A / X / Y");
     CTN_REQUIRE(a.K1 >= 0 && a.K1 <= a.K, "ctn_gemm_nn: K1 out of range");

@@ -503,7 +503,7 @@ def gemm_nn(M, T, K, batch, A, lda, X, Y, *, A2=None, lda2=0, K1=None, Xb=None, 
             A_prep=None, fin=None, prep_kernel=0):
     """Y[b] = A(k-major) . xform(X[b]); see ctn_gemm_nn in include/ctn.h.  X/Xb/X2/Y/Y2/R/E are act views.  A_prep: the
     same A as a prepared matrix (prepared() / weight_prep()); A, A2 may then be None.  prep_kernel: CTN_PREP_* (0 = the
-    library's choice, 1 = wave-split, 2 = block-split kernel for the prepared operand)."""
+    library's choice, 1 = wave-split, 2 = block-split, 3 = eight-wave wave-split kernel for the prepared operand)."""
     lib = _lib.load()
     a = _lib.GemmNNArgs()
     a.tile_width = tile_width or _gemm_tile

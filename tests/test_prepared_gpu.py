@@ -15,9 +15,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 2], ids=["wave_split", "block_split"], autouse=True)
+@pytest.fixture(params=[1, 2, 3], ids=["wave_split", "block_split", "wave_split8"], autouse=True)
 def prep_kernel(request):
-    """Every test runs once per kernel that consumes the prepared operand (CTN_PREP_WAVE_SPLIT, CTN_PREP_BLOCK_SPLIT)."""
+    """Every test runs once per kernel that consumes the prepared operand (CTN_PREP_WAVE_SPLIT, CTN_PREP_BLOCK_SPLIT,
+    CTN_PREP_WAVE_SPLIT8; the last one has its own tile width and ignores the tests' width parameter)."""
     from speech_amd import ops
     before = ops._prep_kernel
     ops._prep_kernel = request.param

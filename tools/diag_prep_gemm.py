@@ -17,7 +17,7 @@ for (M, K) in [(512, 128), (512, 256), (256, 512), (128, 512)]:
     Y = ops.new_act(B, M, T, dev)
     bias = torch.randn(M, device=dev)
     res = []
-    for prep, width in ((0, 0), (1, 128), (1, 64), (2, 128), (2, 64)):
+    for prep, width in ((0, 0), (1, 128), (1, 64), (2, 128), (3, 0)):
         kw = dict(bias=bias, tile_width=width, A_prep=Ap if prep else None, prep_kernel=prep)
         for _ in range(3):
             ops.gemm_nn(M, T, K, B, A, M, X, Y, **kw)
@@ -30,7 +30,7 @@ for (M, K) in [(512, 128), (512, 256), (256, 512), (128, 512)]:
         if prep == 0:
             Yref = Y.clone()
         same = "" if torch.equal(Y, Yref) else " DIFFERS"
-        res.append("%s%s %.0fus %.0fTF%s" % (("split", "wave", "block")[prep], width or "", us,
+        res.append("%s%s %.0fus %.0fTF%s" % (("split", "wave", "block", "wave8x256")[prep], width or "", us,
                                             2.0 * M * K * T * B / us * 1e-6, same))
     out.append("M%dK%d: " % (M, K) + ", ".join(res))
 print(os.environ.get("CTN_LIB", "base").split("/")[-1])

@@ -406,6 +406,9 @@ constexpr int FBM = 128, FBK = 16;
                        // (-6 % per launch).  The variants with a transform lose with the same request (+6 %).
 #endif
 
+#ifndef CTN_NN_WIDE8_MIN_BLOCKS
+#define CTN_NN_WIDE8_MIN_BLOCKS 256   // a launch with fewer tiles than this (the CUs of the chip) takes the next narrower tile
+#endif
 #ifndef CTN_NN_W5
 #define CTN_NN_W5 3      // waves per SIMD of the wave-split prepared variant: its LDS footprint allows three blocks per CU
 #endif
@@ -1409,14 +1412,21 @@ int launch_prep_n(const ctn_gemm_nn_args& a, hipStream_t s) {
 // norm-backward operand: 132 us at 128 columns and two blocks per CU, 149 us at 64 columns and three).
 int launch_prep(const ctn_gemm_nn_args& a, hipStream_t s) {
     // block-split kernel: the second landing tile of the norm-backward operand leaves room for one block per CU at 128
-    const bool narrow = (a.xflags & CTN_XF_NORMBWD) && a.prep_kernel == CTN_PREP_BLOCK_SPLIT;
+    // wave-split kernel: 128 columns unless that leaves CUs without a block (small batches), then 64
+    const bool narrow = a.prep_kernel == CTN_PREP_BLOCK_SPLIT
+                            ? (a.xflags & CTN_XF_NORMBWD) != 0
+                            : (int64_t)ctn_cdiv(a.M, FBM) * ctn_cdiv(a.T, 128) * a.batch < CTN_NN_WIDE8_MIN_BLOCKS;
     const int width = (a.tile_width == 64 || a.tile_width == 128) ? a.tile_width : (narrow ? 64 : 128);
     if (a.prep_kernel == CTN_PREP_BLOCK_SPLIT)
         return width == 128 ? launch_prep_n<128, 4>(a, s) : launch_prep_n<64, 4>(a, s);
     // eight waves over 256 columns unless the caller names a width or a kernel; not with the norm-backward operand,
     // whose second X tile would leave room for one such block per CU
+    // ... and not for launches that would leave CUs without a block of it (small batches): the four-wave kernel's tiles
+    // are half as wide
+    const int64_t blocks8 = (int64_t)ctn_cdiv(a.M, FBM) * ctn_cdiv(a.T, 256) * a.batch;
     const bool wide8 = a.prep_kernel == CTN_PREP_WAVE_SPLIT8 ||
-                       (a.prep_kernel == CTN_PREP_DEFAULT && a.tile_width == 0 && !(a.xflags & CTN_XF_NORMBWD));
+                       (a.prep_kernel == CTN_PREP_DEFAULT && a.tile_width == 0 && !(a.xflags & CTN_XF_NORMBWD) &&
+                        blocks8 >= CTN_NN_WIDE8_MIN_BLOCKS);
     if (wide8) return launch_prep_n<256, 6>(a, s);
     return width == 128 ? launch_prep_n<128, 5>(a, s) : launch_prep_n<64, 5>(a, s);
 }

@@ -16,6 +16,12 @@
 #if defined(CTN_DBG_DW_TEMPORAL)
 #define CTN_DW_LD ctn_ld4
 #define CTN_DW_ST ctn_st4
+#elif defined(CTN_DBG_DW_TEMPORAL_ST)
+#define CTN_DW_LD ctn_ld4_nt
+#define CTN_DW_ST ctn_st4
+#elif defined(CTN_DBG_DW_TEMPORAL_LD)
+#define CTN_DW_LD ctn_ld4
+#define CTN_DW_ST ctn_st4_nt
 #else
 #define CTN_DW_LD ctn_ld4_nt
 #define CTN_DW_ST ctn_st4_nt

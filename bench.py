@@ -9,9 +9,10 @@ synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.  Weak sca
 fixed, value = utterances all ranks processed / max-over-ranks time.
 
 The line also carries
-  roofline      live HIP-event timing of the dominant kernel (the f32-MFMA pointwise-conv GEMM) over one
-                instrumented step: algorithmic FLOPs of its launches / their summed duration, vs the 157.3
-                TFLOP/s dense f32 matrix peak of MI355X;
+  roofline      live HIP-event timing of the dominant kernel (the pointwise-conv GEMM, gemm_nn_fast_kernel) over one
+                instrumented step: algorithmic fp32 FLOPs of its launches / their summed duration, vs the 157.3
+                TFLOP/s dense f32 matrix peak of MI355X (the path computes in fp32; in the default arithmetic each
+                product is formed exactly from six bf16 matrix instructions, whose own issue rate the row also carries);
   roofline_hbm  the same for the fused depthwise kernels against the 8 TB/s HBM3E peak
                 (algorithmic bytes: forward 2 x H x T' x 4, backward 3 x H x T' x 4 per utterance and layer), with the
                 rate of a hand-written 16-byte

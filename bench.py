@@ -69,17 +69,28 @@ def instrumented_step(trainer, mixture, sources):
             rec[name].append((e0, e1, work(*a, **k)))
         return inner
 
-    ops.gemm_nn = wrap("gemm_nn", lambda M, T, K, batch, *a, **k: 2.0 * M * T * K * batch)
-    ops.gemm_nt = wrap("gemm_nt", lambda M, N, T, batch, *a, **k: 2.0 * M * N * T * batch)
-    ops.dw_fwd = wrap("dw_fwd", lambda x, w, bias, y, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
+    wrapped = {}
+    wrapped["gemm_nn"] = wrap("gemm_nn", lambda M, T, K, batch, *a, **k: 2.0 * M * T * K * batch)
+    wrapped["gemm_nt"] = wrap("gemm_nt", lambda M, N, T, batch, *a, **k: 2.0 * M * N * T * batch)
+    wrapped["dw_fwd"] = wrap("dw_fwd", lambda x, w, bias, y, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
     # the backward kernel is priced at 3 tensors (read x, read dy, write dx), which is what it moves: the convolution
     # output is recomputed from x instead of being read
-    ops.dw_bwd = wrap("dw_bwd", lambda dn2, x, *a, **k: 3.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
+    wrapped["dw_bwd"] = wrap("dw_bwd", lambda dn2, x, *a, **k: 3.0 * x.shape[0] * x.shape[1] * x.shape[2] * 4)
     # per-kernel timing needs eager launches on ONE stream (two sub-batch streams overlap kernels, which makes a
     # kernel's own duration meaningless); the work is the same full per-GPU batch
     graph_mode, trainer.use_graph = trainer.use_graph, False
     n_streams, trainer.n_streams = trainer.n_streams, 1
     try:
+        # one eager step first, with the original entry points: the eager mode's activation buffers then come out of
+        # torch's caching allocator as they do in every later step, and the timed launches do not pay for the first
+        # touch of freshly mapped memory
+        for k, f in orig.items():
+            setattr(ops, k, f)
+        trainer.step(mixture, sources)
+        torch.cuda.synchronize()
+        for k in rec:
+            rec[k].clear()
+        ops.gemm_nn, ops.gemm_nt, ops.dw_fwd, ops.dw_bwd = wrapped["gemm_nn"], wrapped["gemm_nt"], wrapped["dw_fwd"], wrapped["dw_bwd"]
         trainer.step(mixture, sources)
         torch.cuda.synchronize()
     finally:
@@ -414,8 +425,8 @@ def main():
             note="achieved = algorithmic fp32 FLOPs (2*M*K*T' per launch and utterance) / summed launch durations; peak = the "
                  "dense f32 matrix peak, the peak of the dtype the path computes in",
             traffic=profiled_traffic("gemm_nn_fast_kernel", args.batch), traffic_source=traffic_file(args.batch),
-            mode="one instrumented step of the same batch, single stream, eager launches (bench.py --streams 1 --no-graph "
-                 "is the profiled command)",
+            mode="one instrumented step of the same batch, single stream, eager launches, after one eager warm-up step "
+                 "(bench.py --streams 1 --no-graph is the profiled command)",
             mfma_bare_loop=round(mfma_bare_loop_rate(device), 1),
             bf16_mfma_bare_loop=round(mfma_bare_loop_rate(device, bf16=True), 1))
         extra["roofline_wgrad"] = rows["gemm_nt"]

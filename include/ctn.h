@@ -297,9 +297,34 @@ typedef struct {
     const float* b_gamma; const float* b_beta;
     float* C;  int64_t ldc;                   /* rows m < M1  (+=) */
     float* C2; int64_t ldc2;                  /* rows m >= M1 (+=) */
+    /* Optional by-products per batch element, for ctn_heads_bwd_coefs below (all NULL to skip; the LDS-DMA kernel only:
+     * M, N, M1 multiples of 16):
+     *   a_rowsum_b[b][m]  += sum_t A'[b][m][t]                                   (float [batch][M], zeroed by the caller)
+     *   wdot_sums[b][slot] += sum_{m,n} Wd[m][n] * (this block's partial of C_b)  (double [batch][CTN_STAT_SLOTS], zeroed)
+     * with Wd = wdot (rows m < M1, pitch ldwd) and wdot2 (rows m >= M1, pitch ldwd2) in the layout of C / C2. */
+    float* a_rowsum_b;
+    const float* wdot;  int64_t ldwd;
+    const float* wdot2; int64_t ldwd2;
+    double* wdot_sums;
 } ctn_gemm_nt_args;
 
 int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream);
+
+/* The backward coefficients of the global layer norm in front of the residual layer's heads, WITHOUT a pass over the
+ * normalised tensor: with dn = W^T dY (the heads' input gradient) and the heads' weight gradient computed per batch
+ * element as G'_b[m][c] = sum_t dY_b[m][t] gamma_c xhat_b[c][t] (ctn_gemm_nt with b_beta = 0),
+ *   S1_b = sum_{c,t} gamma_c dn_b[c][t]           = sum_c gamma_c sum_m W[m][c] R_b[m],   R_b[m] = sum_t dY_b[m][t]
+ *   S2_b = sum_{c,t} gamma_c dn_b[c][t] xhat[c][t] = sum_{m,c} W[m][c] G'_b[m][c]
+ * so c1_b = -rstd_b S1_b / n, c2_b = -rstd_b^2 S2_b / n come from the by-products of the weight-gradient launch
+ * (a_rowsum_b, wdot_sums above) and the heads' input-gradient GEMM needs neither the pre-activation tensor nor a
+ * statistics epilogue.  The same launch restores the beta term the weight gradient was computed without:
+ * dW[m][c] += beta_c sum_b R_b[m] (atomic adds: other streams may be adding to dW).  W / dW: rows m < M1 at
+ * W / dW (pitch ld), rows m >= M1 at W2 / dW2 (pitch ld2).  Replaces the EPI_NORMBWD statistics of the heads'
+ * input-gradient GEMM for gLN; the reference arithmetic is GroupNorm's backward (src/modules/norm.py:18 under autograd). */
+int ctn_heads_bwd_coefs(const float* W, int64_t ld, const float* W2, int64_t ld2, int M, int M1, int H,
+                        const float* gamma, const float* beta, const float* rowsum_b, const double* wdot_sums,
+                        const float* rstd, int batch, double count, float* c1, float* c2, float* dW, int64_t lddw,
+                        float* dW2, int64_t lddw2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layer-norm statistics (src/modules/norm.py:18 nn.GroupNorm(1, C, eps); :78-90 cumulative form)

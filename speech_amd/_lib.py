@@ -91,6 +91,7 @@ class GemmNTArgs(C.Structure):
         ("b_mean", _p), ("b_rstd", _p), ("b_ssb", _i64), ("b_sst", _i64),
         ("b_gamma", _p), ("b_beta", _p),
         ("C", _p), ("ldc", _i64), ("C2", _p), ("ldc2", _i64),
+        ("a_rowsum_b", _p), ("wdot", _p), ("ldwd", _i64), ("wdot2", _p), ("ldwd2", _i64), ("wdot_sums", _p),
     ]
 
 
@@ -165,6 +166,8 @@ PROTOTYPES = {
     "ctn_norm_bwd_reduce": (C.c_int, [_p, _i64, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _i64, _p,
                                       _p, _p, _i64, _p, _p, _p]),
     "ctn_gln_bwd_coefs": (C.c_int, [_p, _p, C.c_int, _f64, _p, _p, _p]),
+    "ctn_heads_bwd_coefs": (C.c_int, [_p, _i64, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_int, _f64,
+                                      _p, _p, _p, _i64, _p, _i64, _p]),
     "ctn_cln_bwd_coefs": (C.c_int, [_p, _i64, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _f32, _p, _p, _p]),
     "ctn_norm_bwd_apply": (C.c_int, [_p, _i64, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _i64, _i64,
                                      _p, _p, _i64, _p, _p]),

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT
     // the two waves of a tile row read the same A rows: one of them reduces, and only in the first tile column
     // (frame-divided pairs read different frames of those rows: both reduce)
     const bool reducer = (tile_n == 0) && (KS || (wave & 1) == 0);
-    const bool do_rowsum = reducer && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr);
+    const bool do_rowsum = reducer && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr || a.a_rowsum_b != nullptr);
     float rowsum[TTM];
 #pragma unroll
     for (int i = 0; i < TTM; ++i) rowsum[i] = 0.f;
@@ -733,8 +733,29 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT
                 } else if (a.a_rowsum2) {
                     atomicAdd(a.a_rowsum2 + (m - M1), sv);
                 }
+                if (a.a_rowsum_b) atomicAdd(a.a_rowsum_b + (int64_t)b * M + m, sv);
             }
         }
+    }
+    // by-product for ctn_heads_bwd_coefs: the block's partial tile of this batch element's C, dotted with Wd
+    if (!BWD && a.wdot_sums != nullptr) {
+        double wd = 0.0;
+#pragma unroll
+        for (int i = 0; i < TTM; ++i)
+#pragma unroll
+            for (int j = 0; j < TTN; ++j) {
+                const int n = n_blk + wn0 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_blk + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < M && n < N) {
+                        const float wv = (m < M1) ? a.wdot[(int64_t)m * a.ldwd + n] : a.wdot2[(int64_t)(m - M1) * a.ldwd2 + n];
+                        wd += (double)acc[i][j][r] * (double)wv;
+                    }
+                }
+            }
+        const double tot = ctn_wave_sum(wd);
+        if (lane == 0) atomicAdd(a.wdot_sums + (int64_t)b * CTN_STAT_SLOTS + ctn_slot(), tot);
     }
     if (BWD && a.a_dalpha != nullptr && tile_n == 0) {
         __shared__ double dred[NTH / 64];
@@ -867,6 +888,11 @@ extern "C" int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream) {
     }
     if (a.bflags & CTN_XF_NORM)
         CTN_REQUIRE(a.b_mean && a.b_rstd && a.b_gamma && a.b_beta, "ctn_gemm_nt: NORM needs stats, gamma, beta");
+    if (a.a_rowsum_b || a.wdot_sums) {
+        CTN_REQUIRE(fast_ok(a) && !(a.aflags & CTN_XF_NORMBWD), "ctn_gemm_nt: the per-batch by-products need the LDS-DMA "
+                    "kernel (M, N, M1 multiples of 16) without the NORMBWD operand");
+        CTN_REQUIRE(!a.wdot_sums || ((a.M1 == 0 || a.wdot) && (a.M1 == a.M || a.wdot2)), "ctn_gemm_nt: wdot_sums needs wdot / wdot2");
+    }
     hipStream_t s = (hipStream_t)stream;
     if (fast_ok(a))
         launch_fast(a, s);

@@ -106,6 +106,46 @@ __global__ void gln_bwd_coefs_kernel(const double* __restrict__ sums, const floa
     c2[b] = (float)(-r * r * S2 / count);
 }
 
+// ctn_heads_bwd_coefs.  Blocks [0, batch): one batch element each -- S1 = sum_c gamma_c sum_m W[m][c] R_b[m] (thread
+// c walks the rows, consecutive threads read consecutive floats), S2 = sum over the slots.  Blocks [batch, batch + M):
+// one weight row each -- dW[m][c] += beta_c sum_b R_b[m].
+constexpr int HC_NT = 256;
+__global__ __launch_bounds__(HC_NT) void heads_bwd_coefs_kernel(
+    const float* __restrict__ W, int64_t ld, const float* __restrict__ W2, int64_t ld2, int M, int M1, int H,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rowsum_b,
+    const double* __restrict__ wdot_sums, const float* __restrict__ rstd, int batch, double count, float* c1, float* c2,
+    float* dW, int64_t lddw, float* dW2, int64_t lddw2) {
+    __shared__ double dred[HC_NT / 64];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < batch) {
+        const int b = blockIdx.x;
+        const float* R = rowsum_b + (int64_t)b * M;
+        double s1 = 0.0;
+        for (int c = tid; c < H; c += HC_NT) {
+            float u = 0.f;
+            for (int m = 0; m < M; ++m) {
+                const float w = (m < M1) ? W[(int64_t)m * ld + c] : W2[(int64_t)(m - M1) * ld2 + c];
+                u = __builtin_fmaf(w, R[m], u);
+            }
+            s1 += (double)gamma[c] * (double)u;
+        }
+        const double S1 = ctn_block_sum_f64(s1, dred);
+        if (tid == 0) {
+            double S2 = 0.0;
+            for (int s = 0; s < CTN_STAT_SLOTS; ++s) S2 += wdot_sums[(int64_t)b * CTN_STAT_SLOTS + s];
+            const double r = rstd[b];
+            c1[b] = (float)(-r * S1 / count);
+            c2[b] = (float)(-r * r * S2 / count);
+        }
+        return;
+    }
+    const int m = (int)blockIdx.x - batch;
+    float db = 0.f;
+    for (int b = 0; b < batch; ++b) db += rowsum_b[(int64_t)b * M + m];
+    float* row = (m < M1) ? dW + (int64_t)m * lddw : dW2 + (int64_t)(m - M1) * lddw2;
+    for (int c = tid; c < H; c += HC_NT) atomicAdd(row + c, beta[c] * db);
+}
+
 // Block-wide exclusive scan of one double per thread (1024 threads); returns the exclusive prefix and
 // writes the block total to *total.
 constexpr int SCAN_NT = 1024;
@@ -395,6 +435,20 @@ int ctn_gln_bwd_coefs(const double* sums, const float* rstd, int batch, double c
     hipLaunchKernelGGL(gln_bwd_coefs_kernel, dim3(ctn_cdiv(batch, 64)), dim3(64), 0, (hipStream_t)stream, sums,
                        rstd, batch, count, c1, c2);
     CTN_CHECK_LAUNCH("ctn_gln_bwd_coefs");
+    return CTN_OK;
+}
+
+int ctn_heads_bwd_coefs(const float* W, int64_t ld, const float* W2, int64_t ld2, int M, int M1, int H,
+                        const float* gamma, const float* beta, const float* rowsum_b, const double* wdot_sums,
+                        const float* rstd, int batch, double count, float* c1, float* c2, float* dW, int64_t lddw,
+                        float* dW2, int64_t lddw2, void* stream) {
+    CTN_REQUIRE(M > 0 && H > 0 && batch > 0 && M1 >= 0 && M1 <= M && count > 0, "ctn_heads_bwd_coefs: bad shape");
+    CTN_REQUIRE((M1 == 0 || (W && dW && ld >= H && lddw >= H)) && (M1 == M || (W2 && dW2 && ld2 >= H && lddw2 >= H)),
+                "ctn_heads_bwd_coefs: W / dW of both row ranges");
+    CTN_REQUIRE(gamma && beta && rowsum_b && wdot_sums && rstd && c1 && c2, "ctn_heads_bwd_coefs: null pointer");
+    hipLaunchKernelGGL(heads_bwd_coefs_kernel, dim3(batch + M), dim3(HC_NT), 0, (hipStream_t)stream, W, ld, W2, ld2, M,
+                       M1, H, gamma, beta, rowsum_b, wdot_sums, rstd, batch, count, c1, c2, dW, lddw, dW2, lddw2);
+    CTN_CHECK_LAUNCH("ctn_heads_bwd_coefs");
     return CTN_OK;
 }
 

@@ -35,6 +35,27 @@ RECOMPUTE_DW_OUTPUT = os.environ.get("CTN_DW_RECOMPUTE", "1") != "0"
 # split of both operands.
 USE_PREPARED_WEIGHTS = os.environ.get("CTN_PREPARED_WEIGHTS", "1") != "0"
 
+# The backward coefficients of the norm in front of a residual layer's heads can be derived from by-products of the heads'
+# weight-gradient launch instead of a statistics epilogue (and a read of the pre-activation tensor) in the heads'
+# input-gradient GEMM (gLN only; ctn_heads_bwd_coefs): 3 % of a training step at the benchmark's batch.  Opt-in
+# (CTN_HEADS_COEFS_FROM_WGRAD=1): every tensor-valued gradient agrees with float64 as before (1.5e-6 of its largest
+# element at the paper width), but the scalar PReLU-slope gradients -- sums in which the three parts of the norm's
+# backward formula cancel -- lose a digit in the three-piece arithmetic (worst of 49 at the paper width, 4 s inputs:
+# 2.6e-3 relative against 1.5e-4 with the epilogue's sums, which are taken from the very tensor the formula is then
+# applied to; with f32 MFMAs both routes are at 1e-4).  tools/diag_heads_coefs.py measures it.
+HEADS_COEFS_FROM_WGRAD = os.environ.get("CTN_HEADS_COEFS_FROM_WGRAD", "0") != "0"
+
+_ZERO_ROWS = {}
+
+
+def _zero_row(n, dev):
+    """A shared all-zero float row of n elements (a beta that is not there)."""
+    key = (n, str(dev))
+    if key not in _ZERO_ROWS:
+        _ZERO_ROWS[key] = torch.zeros(n, device=dev, dtype=torch.float32)
+    return _ZERO_ROWS[key]
+
+
 FLAT_ALIGN = 64      # floats: every tensor of a flat parameter / gradient buffer starts on a 256-byte boundary
 
 
@@ -282,10 +303,40 @@ def layer_backward(L, saved, dout, dskip, sink, dilation, causal, eps):
     H, Bc, Sc, P = L.H, L.Bc, L.Sc, L.P
     o = L.orig
     dual = L.dual and dout is not None
-    # heads: input gradient with the norm-2 backward sums in the epilogue
     dn2 = new_act(B, H, T, dev)
-    bacc2 = Accum(B, T, causal, dev)
     parts = _layer_parts(L)
+    M1 = Bc if dual else 0
+    if HEADS_COEFS_FROM_WGRAD and not causal and ops.heads_coefs_usable(M1 + Sc, M1, H):
+        # The norm-2 backward coefficients come out of the heads' WEIGHT gradient: sum gamma dn xhat = sum W * (the per-
+        # sample weight gradient taken without beta), sum gamma dn = sum_c gamma_c sum_m W[m][c] rowsum[m] (derivation at
+        # ctn_heads_bwd_coefs in include/ctn.h).  The input-gradient GEMM then stores its tile and nothing else: no
+        # read of y2, no statistics in its epilogue.
+        rs_b = ops.zeros((B, M1 + Sc), dev, torch.float32)
+        wsum = ops.zeros((B, ops._lib.STAT_SLOTS), dev, torch.float64)
+        Wo2 = L.Wo.view(Bc, H) if dual else None
+        Ws2 = L.Ws.view(Sc, H)
+        dWo = sink.g(o["Wo"]).view(Bc, H) if dual else None
+        dWs = sink.g(o["Ws"]).view(Sc, H)
+        zb = _zero_row(H, dev)
+        if dual:
+            ops.gemm_nt(Bc + Sc, H, T, B, dout, y2, dWo, H, Ab=dskip, M1=Bc, C2=dWs, ldc2=H, a_rowsum=sink.g(o["bo"]),
+                        a_rowsum2=sink.g(o["bs"]), bflags=XF_PRELU | XF_NORM, b_alpha=L.a2, b_stat=st2,
+                        b_gamma=L.g2.view(-1), b_beta=zb, a_rowsum_b=rs_b, wdot=Wo2, wdot2=Ws2, wdot_sums=wsum)
+        else:
+            ops.gemm_nt(Sc, H, T, B, dskip, y2, dWs, H, a_rowsum=sink.g(o["bs"]), bflags=XF_PRELU | XF_NORM,
+                        b_alpha=L.a2, b_stat=st2, b_gamma=L.g2.view(-1), b_beta=zb, a_rowsum_b=rs_b, wdot=Ws2,
+                        wdot_sums=wsum)
+        ops.heads_bwd_coefs(Wo2 if dual else Ws2, Ws2 if dual else None, L.g2.view(-1), L.be2.view(-1), rs_b, wsum, st2,
+                            B, H, T, dWo if dual else dWs, dWs if dual else None)
+        if dual:
+            Hdp = _prepared(L.planes, "Hd", *parts["Hd"][:2], parts["Hd"][3], dev, K1=Bc)
+            ops.gemm_nn(H, T, Bc + Sc, B, Wo2, H, dout, dn2, A2=Ws2, lda2=H, K1=Bc, Xb=dskip, emode=EPI_STORE, A_prep=Hdp)
+        else:
+            Hdp = None if L.dual else _prepared(L.planes, "Hd", *parts["Hd"][:2], parts["Hd"][3], dev)
+            ops.gemm_nn(H, T, Sc, B, Ws2, H, dskip, dn2, emode=EPI_STORE, A_prep=Hdp)
+        return _layer_backward_tail(L, saved, dn2, dout, dual, sink, dilation, causal, eps, parts)
+    # heads: input gradient with the norm-2 backward sums in the epilogue
+    bacc2 = Accum(B, T, causal, dev)
     finb2 = ops.coefs_request(bacc2, st2, B, H, T)
     if dual:
         Hdp = _prepared(L.planes, "Hd", *parts["Hd"][:2], parts["Hd"][3], dev, K1=Bc)
@@ -304,6 +355,16 @@ def layer_backward(L, saved, dout, dskip, sink, dilation, causal, eps):
                     bflags=XF_PRELU | XF_NORM, b_alpha=L.a2, b_stat=st2, b_gamma=L.g2.view(-1), b_beta=L.be2.view(-1))
     if finb2 is None:
         ops.bwd_coefs(bacc2, st2, B, H, T, eps)
+    return _layer_backward_tail(L, saved, dn2, dout, dual, sink, dilation, causal, eps, parts)
+
+
+def _layer_backward_tail(L, saved, dn2, dout, dual, sink, dilation, causal, eps, parts):
+    """layer_backward from the depthwise convolution down: dn2 (gradient at the norm-2 output) and st2.c1 / c2 are in."""
+    x, y1, y2, st1, st2 = saved
+    B, _, T = x.shape
+    dev = x.device
+    H, Bc, Sc, P = L.H, L.Bc, L.Sc, L.P
+    o = L.orig
     # depthwise backward (+ norm-2 / PReLU-2 backward on load, norm-1 sums on the way out)
     dn1 = new_act(B, H, T, dev)
     bacc1 = Accum(B, T, causal, dev)
@@ -889,7 +950,10 @@ class ConvTasNetFn(torch.autograd.Function):
         dw_dec = new_act(B, N, Tf, dev)
         ops.maskdecode_bwd(dout, pad_left, w, mask, n_src, mp.dec_W.detach(), S, True, dz, dw_dec,
                            sink.g(mp.dec_W).view(N, L))
-        with ops.zero_arena(dev, (2 * len(mp.layers) + 4) * ops.accum_bytes(B, Tf, cfg["causal"])):
+        # (+ per layer the per-sample row sums and dot sums of the heads' weight-gradient launch, HEADS_COEFS_FROM_WGRAD)
+        heads_extra = sum((B * (Lr.Bc + Lr.Sc) * 4 + 255) // 256 * 256 + (B * ops._lib.STAT_SLOTS * 8 + 255) // 256 * 256
+                          for Lr, _ in mp.layers)
+        with ops.zero_arena(dev, (2 * len(mp.layers) + 4) * ops.accum_bytes(B, Tf, cfg["causal"]) + heads_extra):
             dn0, st0 = separator_backward(mp, w, saved, dz, sink, eps)
         ops.encoder_bwd(x2, pad_left, N, L, S, relu, w, sink.g(mp.enc_W).view(N, L), dw_a=dw_dec, dn=dn0, stat=st0,
                         gamma=mp.g0.detach().view(-1), dgamma=sink.g(mp.g0).view(-1), dbeta=sink.g(mp.be0).view(-1))

@@ -470,6 +470,28 @@ def bwd_coefs(acc, stat, B, Cc, T, eps):
     return stat
 
 
+def heads_coefs_usable(M, M1, H):
+    """True when ctn_gemm_nt can deliver the by-products heads_bwd_coefs needs for these head shapes."""
+    return M % 16 == 0 and M1 % 16 == 0 and H % 16 == 0 and M >= 16 and H >= 16
+
+
+def heads_bwd_coefs(W, W2, gamma, beta, rowsum_b, wdot_sums, stat, B, H, T, dW, dW2):
+    """stat.c1, stat.c2 of the gLN in front of the heads from the weight-gradient launch's by-products, and the beta
+    term of the heads' weight gradient (see ctn_heads_bwd_coefs in include/ctn.h).  W / dW: (M1, H) views or None,
+    W2 / dW2: (M - M1, H) views or None."""
+    lib = _lib.load()
+    M1 = 0 if W is None else W.shape[0]
+    M = M1 + (0 if W2 is None else W2.shape[0])
+    stat.c1 = torch.empty_like(stat.mean)
+    stat.c2 = torch.empty_like(stat.mean)
+    _lib.check(lib.ctn_heads_bwd_coefs(_ptr(W), 0 if W is None else W.stride(0), _ptr(W2), 0 if W2 is None else W2.stride(0),
+                                       M, M1, H, _ptr(gamma), _ptr(beta), _ptr(rowsum_b), _ptr(wdot_sums), _ptr(stat.rstd),
+                                       B, float(H) * float(T), _ptr(stat.c1), _ptr(stat.c2), _ptr(dW),
+                                       0 if dW is None else dW.stride(0), _ptr(dW2), 0 if dW2 is None else dW2.stride(0),
+                                       _stream()), "ctn_heads_bwd_coefs")
+    return stat
+
+
 def norm_apply(x, alpha, stat, gamma, beta, y):
     lib = _lib.load()
     B, Cc, T = x.shape
@@ -561,8 +583,11 @@ def pick_kchunk(T, batch, tiles, target_blocks=1024):
 
 def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=0, aflags=0, A2=None,
             a_alpha=None, a_stat=None, a_gamma=None, a_rowsum=None, a_rowsum2=None, a_dalpha=None, bflags=0,
-            b_alpha=None, b_stat=None, b_gamma=None, b_beta=None, kchunk=None):
-    """C[m][n] += sum_b,t xformA(A)[b][m][t] * xformB(B)[b][n][t]; see ctn_gemm_nt in include/ctn.h."""
+            b_alpha=None, b_stat=None, b_gamma=None, b_beta=None, kchunk=None, a_rowsum_b=None, wdot=None, wdot2=None,
+            wdot_sums=None):
+    """C[m][n] += sum_b,t xformA(A)[b][m][t] * xformB(B)[b][n][t]; see ctn_gemm_nt in include/ctn.h.  a_rowsum_b
+    (batch, M) float and wdot / wdot2 (2-D views in C's / C2's layout) with wdot_sums (batch, STAT_SLOTS) double: the
+    per-batch by-products ctn_heads_bwd_coefs consumes, all zeroed by the caller."""
     lib = _lib.load()
     a = _lib.GemmNTArgs()
     a.arith = _arith()
@@ -594,6 +619,11 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
     if b_stat is not None:
         a.b_mean, a.b_rstd, a.b_ssb, a.b_sst = _ptr(b_stat.mean), _ptr(b_stat.rstd), b_stat.sb, b_stat.st
     a.b_gamma, a.b_beta = _ptr(b_gamma), _ptr(b_beta)
+    a.a_rowsum_b, a.wdot_sums = _ptr(a_rowsum_b), _ptr(wdot_sums)
+    if wdot is not None:
+        a.wdot, a.ldwd = _ptr(wdot), wdot.stride(0)
+    if wdot2 is not None:
+        a.wdot2, a.ldwd2 = _ptr(wdot2), wdot2.stride(0)
     a.C, a.ldc = _ptr(Cout), ldc
     a.C2, a.ldc2 = _ptr(C2), ldc2
     _lib.check(lib.ctn_gemm_nt(C.byref(a), _stream()), "ctn_gemm_nt")

@@ -319,12 +319,13 @@ int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream);
  * (a_rowsum_b, wdot_sums above) and the heads' input-gradient GEMM needs neither the pre-activation tensor nor a
  * statistics epilogue.  The same launch restores the beta term the weight gradient was computed without:
  * dW[m][c] += beta_c sum_b R_b[m] (atomic adds: other streams may be adding to dW).  W / dW: rows m < M1 at
- * W / dW (pitch ld), rows m >= M1 at W2 / dW2 (pitch ld2).  Replaces the EPI_NORMBWD statistics of the heads'
- * input-gradient GEMM for gLN; the reference arithmetic is GroupNorm's backward (src/modules/norm.py:18 under autograd). */
+ * W / dW (pitch ld), rows m >= M1 at W2 / dW2 (pitch ld2).  s1acc (batch doubles) and ticket (one 32-bit word) are the
+ * call's work area, zeroed by the caller.  Replaces the EPI_NORMBWD statistics of the heads' input-gradient GEMM for
+ * gLN; the reference arithmetic is GroupNorm's backward (src/modules/norm.py:18 under autograd). */
 int ctn_heads_bwd_coefs(const float* W, int64_t ld, const float* W2, int64_t ld2, int M, int M1, int H,
                         const float* gamma, const float* beta, const float* rowsum_b, const double* wdot_sums,
                         const float* rstd, int batch, double count, float* c1, float* c2, float* dW, int64_t lddw,
-                        float* dW2, int64_t lddw2, void* stream);
+                        float* dW2, int64_t lddw2, double* s1acc, unsigned* ticket, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layer-norm statistics (src/modules/norm.py:18 nn.GroupNorm(1, C, eps); :78-90 cumulative form)

@@ -167,7 +167,7 @@ PROTOTYPES = {
                                       _p, _p, _i64, _p, _p, _p]),
     "ctn_gln_bwd_coefs": (C.c_int, [_p, _p, C.c_int, _f64, _p, _p, _p]),
     "ctn_heads_bwd_coefs": (C.c_int, [_p, _i64, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_int, _f64,
-                                      _p, _p, _p, _i64, _p, _i64, _p]),
+                                      _p, _p, _p, _i64, _p, _i64, _p, _p, _p]),
     "ctn_cln_bwd_coefs": (C.c_int, [_p, _i64, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _f32, _p, _p, _p]),
     "ctn_norm_bwd_apply": (C.c_int, [_p, _i64, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _i64, _i64,
                                      _p, _p, _i64, _p, _p]),

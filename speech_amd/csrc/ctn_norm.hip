@@ -106,44 +106,52 @@ __global__ void gln_bwd_coefs_kernel(const double* __restrict__ sums, const floa
     c2[b] = (float)(-r * r * S2 / count);
 }
 
-// ctn_heads_bwd_coefs.  Blocks [0, batch): one batch element each -- S1 = sum_c gamma_c sum_m W[m][c] R_b[m] (thread
-// c walks the rows, consecutive threads read consecutive floats), S2 = sum over the slots.  Blocks [batch, batch + M):
-// one weight row each -- dW[m][c] += beta_c sum_b R_b[m].
+// ctn_heads_bwd_coefs.  One block per weight row m: v_m = sum_c gamma_c W[m][c] (consecutive threads read consecutive
+// floats), then every batch element's S1 accumulator takes R_b[m] v_m (S1_b = sum_m R_b[m] v_m), and the row of the weight
+// gradient takes beta_c sum_b R_b[m].  The block that finishes last -- a ticket taken after the block's additions have
+// been performed; accumulators and ticket travel through device-scope atomics only -- turns S1 and the slots of S2 into
+// c1, c2 of every batch element.
 constexpr int HC_NT = 256;
 __global__ __launch_bounds__(HC_NT) void heads_bwd_coefs_kernel(
     const float* __restrict__ W, int64_t ld, const float* __restrict__ W2, int64_t ld2, int M, int M1, int H,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rowsum_b,
     const double* __restrict__ wdot_sums, const float* __restrict__ rstd, int batch, double count, float* c1, float* c2,
-    float* dW, int64_t lddw, float* dW2, int64_t lddw2) {
+    float* dW, int64_t lddw, float* dW2, int64_t lddw2, double* s1acc, unsigned* ticket) {
     __shared__ double dred[HC_NT / 64];
-    const int tid = threadIdx.x;
-    if ((int)blockIdx.x < batch) {
-        const int b = blockIdx.x;
-        const float* R = rowsum_b + (int64_t)b * M;
-        double s1 = 0.0;
-        for (int c = tid; c < H; c += HC_NT) {
-            float u = 0.f;
-            for (int m = 0; m < M; ++m) {
-                const float w = (m < M1) ? W[(int64_t)m * ld + c] : W2[(int64_t)(m - M1) * ld2 + c];
-                u = __builtin_fmaf(w, R[m], u);
-            }
-            s1 += (double)gamma[c] * (double)u;
-        }
-        const double S1 = ctn_block_sum_f64(s1, dred);
-        if (tid == 0) {
-            double S2 = 0.0;
-            for (int s = 0; s < CTN_STAT_SLOTS; ++s) S2 += wdot_sums[(int64_t)b * CTN_STAT_SLOTS + s];
-            const double r = rstd[b];
-            c1[b] = (float)(-r * S1 / count);
-            c2[b] = (float)(-r * r * S2 / count);
-        }
-        return;
+    __shared__ double vsh, dbsh;
+    __shared__ unsigned last;
+    const int tid = threadIdx.x, m = blockIdx.x;
+    const float* wrow = (m < M1) ? W + (int64_t)m * ld : W2 + (int64_t)(m - M1) * ld2;
+    double part = 0.0;
+    for (int c = tid; c < H; c += HC_NT) part += (double)gamma[c] * (double)wrow[c];
+    const double v = ctn_block_sum_f64(part, dred);                 // thread 0 holds it
+    if (tid == 0) vsh = v;
+    __syncthreads();
+    double dbp = 0.0;
+    for (int b = tid; b < batch; b += HC_NT) {
+        const double r = rowsum_b[(int64_t)b * M + m];
+        __hip_atomic_fetch_add(s1acc + b, r * vsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dbp += r;
     }
-    const int m = (int)blockIdx.x - batch;
-    float db = 0.f;
-    for (int b = 0; b < batch; ++b) db += rowsum_b[(int64_t)b * M + m];
-    float* row = (m < M1) ? dW + (int64_t)m * lddw : dW2 + (int64_t)(m - M1) * lddw2;
-    for (int c = tid; c < H; c += HC_NT) atomicAdd(row + c, beta[c] * db);
+    const double db = ctn_block_sum_f64(dbp, dred);
+    if (tid == 0) dbsh = db;
+    __syncthreads();
+    float* grow = (m < M1) ? dW + (int64_t)m * lddw : dW2 + (int64_t)(m - M1) * lddw2;
+    const float dbf = (float)dbsh;
+    for (int c = tid; c < H; c += HC_NT) atomicAdd(grow + c, beta[c] * dbf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this block's additions have been performed
+    __syncthreads();
+    if (tid == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)M - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last == 0u) return;
+    for (int b = tid; b < batch; b += HC_NT) {
+        const double S1 = __hip_atomic_load(s1acc + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double S2 = 0.0;
+        for (int sl = 0; sl < CTN_STAT_SLOTS; ++sl) S2 += wdot_sums[(int64_t)b * CTN_STAT_SLOTS + sl];
+        const double r = rstd[b];
+        c1[b] = (float)(-r * S1 / count);
+        c2[b] = (float)(-r * r * S2 / count);
+    }
 }
 
 // Block-wide exclusive scan of one double per thread (1024 threads); returns the exclusive prefix and
@@ -441,13 +449,14 @@ int ctn_gln_bwd_coefs(const double* sums, const float* rstd, int batch, double c
 int ctn_heads_bwd_coefs(const float* W, int64_t ld, const float* W2, int64_t ld2, int M, int M1, int H,
                         const float* gamma, const float* beta, const float* rowsum_b, const double* wdot_sums,
                         const float* rstd, int batch, double count, float* c1, float* c2, float* dW, int64_t lddw,
-                        float* dW2, int64_t lddw2, void* stream) {
+                        float* dW2, int64_t lddw2, double* s1acc, unsigned* ticket, void* stream) {
     CTN_REQUIRE(M > 0 && H > 0 && batch > 0 && M1 >= 0 && M1 <= M && count > 0, "ctn_heads_bwd_coefs: bad shape");
+    CTN_REQUIRE(s1acc && ticket, "ctn_heads_bwd_coefs: needs the zeroed work area (s1acc[batch] doubles, one ticket word)");
     CTN_REQUIRE((M1 == 0 || (W && dW && ld >= H && lddw >= H)) && (M1 == M || (W2 && dW2 && ld2 >= H && lddw2 >= H)),
                 "ctn_heads_bwd_coefs: W / dW of both row ranges");
     CTN_REQUIRE(gamma && beta && rowsum_b && wdot_sums && rstd && c1 && c2, "ctn_heads_bwd_coefs: null pointer");
-    hipLaunchKernelGGL(heads_bwd_coefs_kernel, dim3(batch + M), dim3(HC_NT), 0, (hipStream_t)stream, W, ld, W2, ld2, M,
-                       M1, H, gamma, beta, rowsum_b, wdot_sums, rstd, batch, count, c1, c2, dW, lddw, dW2, lddw2);
+    hipLaunchKernelGGL(heads_bwd_coefs_kernel, dim3(M), dim3(HC_NT), 0, (hipStream_t)stream, W, ld, W2, ld2, M, M1, H,
+                       gamma, beta, rowsum_b, wdot_sums, rstd, batch, count, c1, c2, dW, lddw, dW2, lddw2, s1acc, ticket);
     CTN_CHECK_LAUNCH("ctn_heads_bwd_coefs");
     return CTN_OK;
 }

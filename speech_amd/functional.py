@@ -951,7 +951,8 @@ class ConvTasNetFn(torch.autograd.Function):
         ops.maskdecode_bwd(dout, pad_left, w, mask, n_src, mp.dec_W.detach(), S, True, dz, dw_dec,
                            sink.g(mp.dec_W).view(N, L))
         # (+ per layer the per-sample row sums and dot sums of the heads' weight-gradient launch, HEADS_COEFS_FROM_WGRAD)
-        heads_extra = sum((B * (Lr.Bc + Lr.Sc) * 4 + 255) // 256 * 256 + (B * ops._lib.STAT_SLOTS * 8 + 255) // 256 * 256
+        heads_extra = sum((B * (Lr.Bc + Lr.Sc) * 4 + 255) // 256 * 256 + (B * ops._lib.STAT_SLOTS * 8 + 255) // 256 * 256 +
+                          ((B + 1) * 8 + 255) // 256 * 256
                           for Lr, _ in mp.layers)
         with ops.zero_arena(dev, (2 * len(mp.layers) + 4) * ops.accum_bytes(B, Tf, cfg["causal"]) + heads_extra):
             dn0, st0 = separator_backward(mp, w, saved, dz, sink, eps)

@@ -484,11 +484,12 @@ def heads_bwd_coefs(W, W2, gamma, beta, rowsum_b, wdot_sums, stat, B, H, T, dW, 
     M = M1 + (0 if W2 is None else W2.shape[0])
     stat.c1 = torch.empty_like(stat.mean)
     stat.c2 = torch.empty_like(stat.mean)
+    work = zeros((B + 1,), rowsum_b.device, torch.float64)            # S1 accumulators and, in the last slot, the ticket
     _lib.check(lib.ctn_heads_bwd_coefs(_ptr(W), 0 if W is None else W.stride(0), _ptr(W2), 0 if W2 is None else W2.stride(0),
                                        M, M1, H, _ptr(gamma), _ptr(beta), _ptr(rowsum_b), _ptr(wdot_sums), _ptr(stat.rstd),
                                        B, float(H) * float(T), _ptr(stat.c1), _ptr(stat.c2), _ptr(dW),
                                        0 if dW is None else dW.stride(0), _ptr(dW2), 0 if dW2 is None else dW2.stride(0),
-                                       _stream()), "ctn_heads_bwd_coefs")
+                                       work.data_ptr(), work.data_ptr() + 8 * B, _stream()), "ctn_heads_bwd_coefs")
     return stat
 
 

@@ -409,6 +409,9 @@ constexpr int FBM = 128, FBK = 16;
 #ifndef CTN_NN_WIDE8_MIN_BLOCKS
 #define CTN_NN_WIDE8_MIN_BLOCKS 256   // a launch with fewer tiles than this (the CUs of the chip) takes the next narrower tile
 #endif
+#ifndef CTN_NN_PLAIN_BELOW_BLOCKS
+#define CTN_NN_PLAIN_BELOW_BLOCKS 768   // fewer 128 x 128 tiles than this: the in-kernel split, when the plain operand is there
+#endif
 #ifndef CTN_NN_W5
 #define CTN_NN_W5 3      // waves per SIMD of the wave-split prepared variant: its LDS footprint allows three blocks per CU
 #endif
@@ -1512,7 +1515,14 @@ extern "C" int ctn_gemm_nn(const ctn_gemm_nn_args* args, void* stream) {
                      (a.K1 == a.K || (ctn_aligned16(a.A2) && a.lda2 % 4 == 0));
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (a.A_prep)
+    // A launch too small to give every CU a block of the prepared-operand kernels (small batches) runs better on the
+    // in-kernel split, whose narrower tiles and four blocks per CU fill the chip: taken when the caller also passed the
+    // plain operand (the results are bit-identical either way).
+    const bool small_launch = (int64_t)ctn_cdiv(a.M, FBM) * ctn_cdiv(a.T, 128) * a.batch < CTN_NN_PLAIN_BELOW_BLOCKS;
+    const int64_t desc_lim = 0x40000000 / 4 - 4096;       // (floats inside one buffer descriptor, as in fast_ok)
+    const bool plain_ok = a.A && ctn_aligned16(a.A) && a.lda % 4 == 0 && (int64_t)a.K * a.lda < desc_lim &&
+                          (a.K1 == a.K || (a.A2 && ctn_aligned16(a.A2) && a.lda2 % 4 == 0 && (int64_t)a.K * a.lda2 < desc_lim));
+    if (a.A_prep && !(small_launch && plain_ok && a.prep_kernel == CTN_PREP_DEFAULT && a.tile_width == 0))
         rc = launch_prep(a, s);
     else if (fast_ok(a))
         rc = launch_fast(a, s);

@@ -194,6 +194,7 @@ class PreparedWeights:
         self.t_items = ops.transpose_items(entries)
         # ---- prepared planes
         self.items = None
+        self.planes = bool(planes)             # whether they were asked for (no matrix may qualify: items stays None)
         if planes:
             specs = []
             for i, (L, _) in enumerate(mp.layers):

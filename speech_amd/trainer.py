@@ -72,7 +72,12 @@ class FlatTrainer:
         # running -- one region per TCN block, in the order the backward pass completes them (last block first) -- on
         # the process group's own stream, instead of in one piece after the pass.  It needs the collectives between
         # the kernel launches, so it applies to eager launches; with use_graph the whole pass is one graph replay and
-        # the exchange follows it (n_buckets pieces in flight together).  None = overlap whenever launches are eager.
+        # the exchange follows it (n_buckets pieces in flight together).  Opt-in (True): the default, None or False,
+        # is the exchange after the pass.  The overlapped form issues asynchronous collectives from inside the
+        # autograd pass on a side stream; its host-copy (gloo) branch is exercised by the two-rank tests, its RCCL
+        # branch has not run on more than one GPU, and a wrong stream dependency there would clip and step on partly
+        # reduced gradients without any error -- so it stays off until a multi-GPU run has held it to the
+        # single-process update.
         self.overlap_exchange = overlap_exchange
         self._pending = []
         if not model._fused_ok() or model.dec_basis != 'trainable':
@@ -171,8 +176,6 @@ class FlatTrainer:
     def _overlapping(self):
         if self.world == 1:
             return False
-        if self.overlap_exchange is None:
-            return not self.use_graph
         return bool(self.overlap_exchange) and not self.use_graph
 
     def _exchange_region(self, start, end, ready_streams):
@@ -210,7 +213,7 @@ class FlatTrainer:
         regions = self._region_table() if overlap else []
         hook_layers = {first: k for k, (first, _, _, _) in enumerate(regions) if first is not None}
         self._exchanged = False
-        if self._prepared.items is None and functional.USE_PREPARED_WEIGHTS:     # switched on after construction
+        if not self._prepared.planes and functional.USE_PREPARED_WEIGHTS:        # switched on after construction
             self._prepared = PreparedWeights(ModelParams(self.params, self.model.fused_config()), planes=True)
         self._prepared.refresh()                   # on the stream every sub-batch stream waits for below
         planes = self._prepared

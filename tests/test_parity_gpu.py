@@ -225,6 +225,48 @@ def test_train_two_steps_golden(golden):
             assert (diff > 1e-4).float().mean().item() <= 0.02, "param {} step {}: too many".format(k, step + 1)
 
 
+@pytest.mark.parametrize("name,cfg_name", [("e2e_paper", "CONFIG_PAPER"), ("e2e_paper_causal3_full", "CONFIG_CAUSAL3")])
+def test_train_one_step_paper_width_golden(golden, name, cfg_name):
+    """One FlatTrainer step (clip 5, Adam 1e-3) at the paper width against the parameters the reference holds after
+    its own first update (egs/wsj0-mix/common/src/driver.py:146-155), 343 tensors as sum / abs-sum / 16 strided samples.
+    Adam's first step moves every element by lr * g / (|g| + eps), i.e. by lr * sign(g) wherever |g| >> 1e-8: elements
+    whose gradient is at rounding level may take the other sign and land 2 * lr away, every other element must agree to
+    1e-5.  Bars: a strided sample either agrees to 1e-5 or is one such flip (at most 1 of 16 per tensor); the sums may
+    differ by the flips of at most 0.2 % of the tensor's elements (two elements for small tensors); scalars (PReLU
+    slopes, whose gradients are sums over the whole batch) must agree to 1e-5 outright."""
+    from speech_amd.criterion.pit import PIT1d
+    from speech_amd.criterion.sdr import NegSISDR
+    from speech_amd.trainer import FlatTrainer
+    cfg = getattr(O, cfg_name)
+    lr = 1e-3
+    g = golden(name)
+    model = load_state(build(cfg), cases.e2e_state(cfg))
+    tr = FlatTrainer(model, PIT1d(NegSISDR(), cfg["n_sources"]), lr=lr, max_norm=5.0)
+    mixture, sources = cases.e2e_batch(cfg, int(g["batch"]), int(g["T"]), 0)
+    loss, perm = tr.step(mixture.to(dev()), sources.to(dev()))
+    torch.cuda.synchronize()
+    assert np.array_equal(perm.cpu().numpy(), g["perm"])
+    assert_close(loss, g["loss"], TOL, "loss")
+    n_checked = flips_seen = 0
+    for k, v in model.state_dict().items():
+        ref = g["param_step1." + k]
+        cs = cases.checksum(v)
+        n = v.numel()
+        d = np.abs(cs[2:] - ref[2:])
+        if n == 1:
+            assert d.max() <= 1e-5, "scalar {} after one step: {}".format(k, d.max())
+            continue
+        flipped = (d > 1e-5)
+        assert np.all(np.abs(d[flipped] - 2 * lr) <= 2e-5), "{}: a sample differs by {} (neither equal nor a sign flip)".format(k, d.max())
+        assert flipped.sum() <= 1, "{}: {} of 16 samples flipped".format(k, int(flipped.sum()))
+        allowed = 2 * lr * max(2.0, 0.002 * n) + 1e-6 * n
+        assert abs(cs[0] - ref[0]) <= allowed, "{}: sum differs by {} (> {})".format(k, abs(cs[0] - ref[0]), allowed)
+        assert abs(cs[1] - ref[1]) <= allowed, "{}: abs-sum differs by {} (> {})".format(k, abs(cs[1] - ref[1]), allowed)
+        n_checked += 1
+        flips_seen += int(flipped.sum())
+    assert n_checked >= 290
+
+
 @pytest.mark.parametrize("mode", ["graph", "streams", "graph+streams"])
 def test_trainer_execution_modes_match_eager(mode):
     """HIP-graph replay of the forward/backward pass and sub-batches on separate streams are scheduling choices:
@@ -454,12 +496,15 @@ def test_ragged_minimal_and_long_inputs_vs_float64(cfg_name, batch, T):
     # Scalar slope gradients are sums over a whole tensor whose terms cancel; for some of them the result is so much
     # smaller than its terms that fp32 rounding alone moves it by more than 3e-4 -- in ANY fp32 implementation.  The
     # oracle run in fp32 measures that floor: a scalar is held to 3e-4 or three times the fp32 oracle's own deviation
-    # from float64, whichever is larger.
+    # from float64, whichever is larger -- capped at 3e-3, and the fp32 oracle's own floor must stay below 1.5e-3: a case
+    # so ill-conditioned that it does not would make the adaptive bar vacuous and has to be replaced, not tolerated.
     _, _, _, g32 = O.loss_and_grads(mixture, sources, sd, cfg)
     for k, p in model.named_parameters():
         tol = TOL
         if p.numel() == 1:
-            tol = max(3e-4, 3.0 * rel_err(g32[k], g64[k]))
+            floor = rel_err(g32[k], g64[k])
+            assert floor <= 1.5e-3, "fp32 oracle floor of scalar {} is {}: the case is too ill-conditioned to test".format(k, floor)
+            tol = min(3e-3, max(3e-4, 3.0 * floor))
         assert_close(p.grad, g64[k], tol, "grad " + k)
 
 

@@ -124,3 +124,42 @@ def test_two_ranks_every_exchange_schedule_equals_global_batch(tmp_path):
             # four Adam steps; gradients are summed in a different order (atomics, two shards), and a step moves a weight by
             # about lr * sign-like(g), so a rounding-level change of a near-zero gradient component shows at the 1e-5 level
             assert d <= 2e-5, "{}: {} differs from the global-batch update by {}".format(name, k, d)
+
+
+def _bench_worker(rank, world, port, out_dir, extra):
+    """bench.main() as one rank of a two-rank job: every rank on cuda:0 over gloo (CTN_BENCH_REHEARSAL), the command
+    line the scaling run uses, rank 0's stdout captured to a file."""
+    _paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), CTN_BENCH_REHEARSAL="gloo")
+    import contextlib
+    import bench
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "2"] + list(extra)
+    with open(os.path.join(out_dir, "rank{}.out".format(rank)), "w") as f, contextlib.redirect_stdout(f):
+        bench.main()
+
+
+@pytest.mark.parametrize("extra", [(), ("--profile-eager",)], ids=["default", "profile_eager"])
+def test_bench_two_rank_rehearsal_prints_one_complete_line(tmp_path, extra):
+    """The multi-rank control flow of bench.py (process group, weight broadcast, graph capture beside the group, bucketed
+    exchange behind the replay, max-over-ranks timing, the guarded informational part) with two ranks on the one GPU:
+    rank 0 prints exactly one JSON line with the contract's fields, the other rank prints nothing."""
+    import json
+    world, port = 2, 31700 + (os.getpid() % 2000)
+    mp.start_processes(_bench_worker, args=(world, port, str(tmp_path), extra), nprocs=world, join=True, start_method="spawn")
+    lines = [ln for ln in open(os.path.join(str(tmp_path), "rank0.out")).read().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    assert open(os.path.join(str(tmp_path), "rank1.out")).read().strip() == ""
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2e-3)) <= 1e-2 * line["value"]
+    assert line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
+    assert "4 bucket" in line["config"]["exchange"] and line["config"]["hip_graph"] is True
+    assert "errors" not in line, line.get("errors")
+    if extra:
+        assert line["roofline"]["frac"] <= 1.0 and line["roofline_shapes"]
+    else:
+        assert line["roofline"] is None

@@ -1,6 +1,9 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE counter_collection CSVs).
 FETCH_SIZE (KB) is doubled: on gfx950 it tallies the 128-byte requests of wide streaming reads at 64 bytes.
-usage: summarize_pmc.py fetch.csv write.csv [out.json [batch_per_gpu]]"""
+Besides the per-kernel averages the summary carries `sequence`: for the GEMM and depthwise kernel families the bytes of
+every launch of ONE pass in launch order (averaged over the passes of the run), so that bench.py can attribute traffic
+to the launch shapes of a residual layer although several shapes share one kernel instance.
+usage: summarize_pmc.py fetch.csv write.csv [out.json [batch_per_gpu [passes]]]"""
 import collections, csv, json, re, sys
 
 
@@ -16,6 +19,37 @@ def load(path, cname):
     return agg
 
 
+FAMILIES = {"gemm_nn": "gemm_nn", "gemm_nt": "gemm_nt", "dw_fwd": "dw_fwd", "dw_bwd": "dw_bwd"}
+
+
+def load_sequence(path, cname, scale):
+    """family -> [bytes of each dispatch, in dispatch order]"""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == cname:
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"]) * 1024.0 * scale))
+    rows.sort()
+    seq = collections.defaultdict(list)
+    for _, name, v in rows:
+        for fam, key in FAMILIES.items():
+            if key in name:
+                seq[fam].append(v)
+                break
+    return seq
+
+
+def per_pass(seq, passes):
+    """Average over the passes, position by position; families whose launch count is not a multiple of `passes` are left out."""
+    out = {}
+    for fam, vals in seq.items():
+        if not vals or len(vals) % passes:
+            continue
+        n = len(vals) // passes
+        out[fam] = [sum(vals[p * n + i] for p in range(passes)) / passes for i in range(n)]
+    return out
+
+
 fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(fe, key=lambda k: -fe[k][1]):
@@ -28,6 +62,11 @@ for k, d in list(out.items())[:16]:
     print("%-46s launches %4d  read %8.1f MB  write %8.1f MB per launch" %
           (k[:46], d["launches"], d["read_bytes_per_launch"] / 1e6, d["write_bytes_per_launch"] / 1e6))
 if len(sys.argv) > 3:
+    passes = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    rseq = per_pass(load_sequence(sys.argv[1], "FETCH_SIZE", 2.0), passes)
+    wseq = per_pass(load_sequence(sys.argv[2], "WRITE_SIZE", 1.0), passes)
+    sequence = {fam: [round(a + b) for a, b in zip(rseq[fam], wseq[fam])]
+                for fam in rseq if fam in wseq and len(rseq[fam]) == len(wseq[fam])}
     doc = {
         "batch_per_gpu": int(sys.argv[4]) if len(sys.argv) > 4 else 32,
         "command": "bench.py --steps 1 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --no-split-probe --no-recipe-batch "
@@ -36,6 +75,8 @@ if len(sys.argv) > 3:
                       "FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16-byte-per-lane streaming reads at 64 "
                       "bytes); kernels that read 4 bytes per lane (maskdecode_*, encoder_bwd) are over-counted by that "
                       "correction",
+        "passes": passes,
         "kernels": out,
+        "sequence": sequence,
     }
     json.dump(doc, open(sys.argv[3], "w"), indent=1)

@@ -13,6 +13,7 @@ device memory, the current stream and the autograd graph edges.  Data flow of on
 
 Only y1, y2 and the per-norm statistics are kept for backward; normalised tensors never exist in HBM.
 """
+import collections
 import os
 
 import torch
@@ -136,15 +137,43 @@ def _flat(p):
     return None if p is None else p.detach().reshape(-1)
 
 
+# Prepared matrices made outside a PreparedWeights store (module-by-module passes: validation, ResidualBlock1d or
+# Conv1d on their own) are kept per source tensor and reused while the sources have not changed: keyed on address,
+# layout and torch's version counter, which every in-place update through torch bumps (optimizers, load_state_dict,
+# copy_); at most _PREP_CACHE_MAX matrices, least recently used first out.  An update that writes through a raw pointer does not -- FlatTrainer's fused Adam kernel -- and must call
+# invalidate_prepared_cache(), which FlatTrainer.optimizer_step does.
+_PREP_CACHE = collections.OrderedDict()
+_PREP_CACHE_MAX = 512
+
+
+def invalidate_prepared_cache():
+    _PREP_CACHE.clear()
+
+
 def _prepared(store, key, K, M, parts, dev, K1=None):
     """The prepared form of a K x M weight operand (parts: [(2-D source view, transpose, k_off, m_off)]) or None when
     this arithmetic / shape does not take one.  `store` (a dict of matrices prepared earlier in the step) is used when
-    it has the key."""
+    it has the key; otherwise the matrix comes from the per-tensor cache above or is prepared now."""
     if not (USE_PREPARED_WEIGHTS and ops.prep_usable(M, K, K1)):
         return None
     if store is not None and store.get(key) is not None:
         return store[key]
-    return ops.prepared(K, M, parts, dev)
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():      # a graph's private pool must not
+                                                                                    # leak into the cache
+        return ops.prepared(K, M, parts, dev)
+    ck = (K, M, str(dev)) + tuple((src.data_ptr(), src._version, tuple(src.shape), src.stride(), bool(tr), ko, mo)
+                                  for src, tr, ko, mo in parts)
+    hit = _PREP_CACHE.get(ck)
+    if hit is not None:
+        _PREP_CACHE.move_to_end(ck)
+        return hit[0]
+    out = ops.prepared(K, M, parts, dev)
+    # the entry holds the source views: their storage cannot be freed and its address handed to another tensor (with an
+    # equal version count) while the key is in the cache
+    _PREP_CACHE[ck] = (out, [src for src, _, _, _ in parts])
+    while len(_PREP_CACHE) > _PREP_CACHE_MAX:
+        _PREP_CACHE.popitem(last=False)
+    return out
 
 
 def _layer_parts(L):
@@ -509,10 +538,16 @@ class LstmFn(torch.autograd.Function):
         whh = torch.stack(w_hh).contiguous()                              # (D, 4H, H)
         hout, save = ops.lstm_fwd(xproj, whh)
         ctx.saved = (x2, w_ih_all, whh, hout, save, n_dir, (N, T, F_in, H))
-        return hout.view(N, T, n_dir * H)
+        # final states as nn.LSTM returns them, (D, N, H): the forward direction's last step, the reverse direction's
+        # first (the step it consumes last); the cell state is the fifth saved plane.  Not differentiated.
+        last = [T - 1, 0][:n_dir]
+        h_n = torch.stack([hout[:, t, d] for d, t in enumerate(last)])
+        c_n = torch.stack([save[:, t, d, 4] for d, t in enumerate(last)])
+        ctx.mark_non_differentiable(h_n, c_n)
+        return hout.view(N, T, n_dir * H), h_n, c_n
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dh_n=None, _dc_n=None):
         x2, w_ih_all, whh, hout, save, n_dir, (N, T, F_in, H) = ctx.saved
         dgates, db_all = ops.lstm_bwd(dout.contiguous().float().view(N, T, n_dir, H), save, whh)      # (N, T, D, 4H), (D, 4H)
         db_all = db_all.view(-1)

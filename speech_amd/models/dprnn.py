@@ -12,6 +12,9 @@ with the input projection of all steps and the weight gradients as single large 
 kernels as well, and so are the axis shuffles between the two layouts (tiled transposes, ctn_permute); the linear layer
 is torch's (a plain library GEMM).
 """
+import warnings
+
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -24,19 +27,31 @@ EPS = 1e-12
 class LSTM(nn.LSTM):
     """nn.LSTM as a parameter container -- same names, shapes and initialisation, so checkpoints interchange with the
     reference's -- with the forward pass on the persistent recurrence kernels.  What those kernels do not cover (an
-    initial state, several layers, projections, hidden sizes above 128 or not a multiple of 4, time-major input) takes
-    nn.LSTM's own forward, i.e. the GPU library's LSTM."""
+    initial state, several layers, projections, hidden sizes above 128 or not a multiple of 4, time-major or packed
+    input, other dtypes than fp32) takes nn.LSTM's own forward, i.e. the GPU library's LSTM, and says so once per
+    module with a warning: that path is not this package's kernels."""
+
+    _warned = False
 
     def _persistent_ok(self, input, hx):
-        return (hx is None and input.is_cuda and input.dim() == 3 and self.batch_first and self.num_layers == 1
+        return (hx is None and isinstance(input, torch.Tensor) and input.is_cuda and input.dim() == 3
+                and input.dtype == torch.float32 and all(w.dtype == torch.float32 for w in self._flat_weights)
+                and self.batch_first and self.num_layers == 1
                 and self.bias and not self.proj_size and self.hidden_size <= ops.LSTM_MAX_HIDDEN
                 and self.hidden_size % 4 == 0 and (not self.training or self.dropout == 0.0))
 
     def forward(self, input, hx=None):
         if not self._persistent_ok(input, hx):
+            if not self._warned:
+                self._warned = True
+                warnings.warn("speech_amd LSTM: this call is outside what the persistent recurrence kernels cover (one "
+                              "layer, fp32, batch_first 3-D tensor input, hidden size <= {} and a multiple of 4, no initial "
+                              "state, no projection); it runs on torch.nn.LSTM's library kernels instead"
+                              .format(ops.LSTM_MAX_HIDDEN), RuntimeWarning, stacklevel=2)
             return super().forward(input, hx)
-        output = LstmFn.apply(input, 2 if self.bidirectional else 1, *self._flat_weights)
-        return output, None                          # the final (h, c) pair is not formed: the dual-path blocks drop it
+        n_dir = 2 if self.bidirectional else 1
+        output, h_n, c_n = LstmFn.apply(input, n_dir, *self._flat_weights)
+        return output, (h_n, c_n)
 
     def flatten_parameters(self):
         """The library LSTM wants its weights in one buffer; the persistent kernels read them where they are."""

@@ -293,6 +293,8 @@ class FlatTrainer:
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.sumsq if use_clip else None,
                       self.max_norm if use_clip else 0.0, 1.0 / self.world, self.lr, self.betas[0], self.betas[1],
                       self.eps, self.step_count)
+        # the kernel wrote the parameters through raw pointers: torch's version counters did not move
+        functional.invalidate_prepared_cache()
 
     def step(self, mixture, sources):
         """One optimizer step; returns the (device) loss of this rank's shard and the permutations."""

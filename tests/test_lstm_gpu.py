@@ -26,12 +26,13 @@ def test_lstm_matches_float64(N, T, F, H, bidir):
     mod.to(DEV)
     x = synth.normal((N, T, F), 7).double().requires_grad_(True)
     gy = synth.normal((N, T, (2 if bidir else 1) * H), 8).double()
-    y64, _ = ref(x)
+    y64, (h64, c64) = ref(x)
     (y64 * gy).sum().backward()
     xg = x.detach().float().to(DEV).requires_grad_(True)
     assert mod._persistent_ok(xg, None)
-    y, state = mod(xg)
-    assert state is None
+    y, (h_n, c_n) = mod(xg)                    # the final states, as nn.LSTM returns them
+    assert_close(h_n, h64, 2e-5, "h_n")
+    assert_close(c_n, c64, 2e-5, "c_n")
     (y * gy.float().to(DEV)).sum().backward()
     torch.cuda.synchronize()
     assert_close(y, y64, 2e-5, "h")
@@ -45,5 +46,13 @@ def test_lstm_falls_back_to_the_library_for_what_the_kernels_do_not_cover():
     mod = LSTM(8, 160, batch_first=True, bidirectional=True).to(DEV)       # hidden size above the kernels' 128
     x = synth.normal((4, 6, 8), 3).to(DEV)
     assert not mod._persistent_ok(x, None)
-    y, (h, c) = mod(x)
+    with pytest.warns(RuntimeWarning, match="library kernels"):
+        y, (h, c) = mod(x)
     assert tuple(y.shape) == (4, 6, 320) and tuple(h.shape) == (2, 4, 160)
+    # other dtypes and packed input are outside the kernels as well, and must not reach them
+    small = LSTM(8, 16, batch_first=True).to(DEV)
+    assert small._persistent_ok(x, None)
+    assert not small._persistent_ok(x.double(), None)
+    assert not small.double()._persistent_ok(x, None)
+    packed = nn.utils.rnn.pack_padded_sequence(x.double(), torch.tensor([6, 5, 3, 1]), batch_first=True)
+    assert not small._persistent_ok(packed, None)

@@ -229,11 +229,13 @@ def test_train_two_steps_golden(golden):
 def test_train_one_step_paper_width_golden(golden, name, cfg_name):
     """One FlatTrainer step (clip 5, Adam 1e-3) at the paper width against the parameters the reference holds after
     its own first update (egs/wsj0-mix/common/src/driver.py:146-155), 343 tensors as sum / abs-sum / 16 strided samples.
-    Adam's first step moves every element by lr * g / (|g| + eps), i.e. by lr * sign(g) wherever |g| >> 1e-8: elements
-    whose gradient is at rounding level may take the other sign and land 2 * lr away, every other element must agree to
-    1e-5.  Bars: a strided sample either agrees to 1e-5 or is one such flip (at most 1 of 16 per tensor); the sums may
-    differ by the flips of at most 0.2 % of the tensor's elements (two elements for small tensors); scalars (PReLU
-    slopes, whose gradients are sums over the whole batch) must agree to 1e-5 outright."""
+    Adam's first step moves every element by lr * g / (|g| + 1e-8): by lr * sign(g) wherever |g| >> 1e-8, and by anything
+    in between for the few elements whose gradient is at that level -- there a rounding-level difference of the gradient
+    (relative to the tensor's largest) decides the sign or the size of the move, so such an element may land up to
+    2 * lr away; every other element must agree to 1e-5.  Bars: per tensor at most 1 of the 16 strided samples off by
+    more than 1e-5 and none by more than 2.1 * lr; over all tensors at most 1 % of the samples off; the sums may differ
+    by the moves of at most 0.2 % of the tensor's elements (two elements for small tensors); scalars (PReLU slopes,
+    whose gradients are sums over the whole batch) must agree to 1e-5 outright."""
     from speech_amd.criterion.pit import PIT1d
     from speech_amd.criterion.sdr import NegSISDR
     from speech_amd.trainer import FlatTrainer
@@ -247,7 +249,7 @@ def test_train_one_step_paper_width_golden(golden, name, cfg_name):
     torch.cuda.synchronize()
     assert np.array_equal(perm.cpu().numpy(), g["perm"])
     assert_close(loss, g["loss"], TOL, "loss")
-    n_checked = flips_seen = 0
+    n_checked = off_seen = 0
     for k, v in model.state_dict().items():
         ref = g["param_step1." + k]
         cs = cases.checksum(v)
@@ -256,14 +258,15 @@ def test_train_one_step_paper_width_golden(golden, name, cfg_name):
         if n == 1:
             assert d.max() <= 1e-5, "scalar {} after one step: {}".format(k, d.max())
             continue
-        flipped = (d > 1e-5)
-        assert np.all(np.abs(d[flipped] - 2 * lr) <= 2e-5), "{}: a sample differs by {} (neither equal nor a sign flip)".format(k, d.max())
-        assert flipped.sum() <= 1, "{}: {} of 16 samples flipped".format(k, int(flipped.sum()))
+        off = (d > 1e-5)
+        assert d.max() <= 2.1 * lr, "{}: a sample differs by {} (more than a sign flip of the update)".format(k, d.max())
+        assert off.sum() <= 1, "{}: {} of 16 samples differ".format(k, int(off.sum()))
         allowed = 2 * lr * max(2.0, 0.002 * n) + 1e-6 * n
         assert abs(cs[0] - ref[0]) <= allowed, "{}: sum differs by {} (> {})".format(k, abs(cs[0] - ref[0]), allowed)
         assert abs(cs[1] - ref[1]) <= allowed, "{}: abs-sum differs by {} (> {})".format(k, abs(cs[1] - ref[1]), allowed)
         n_checked += 1
-        flips_seen += int(flipped.sum())
+        off_seen += int(off.sum())
+    assert off_seen <= 0.01 * 16 * n_checked, "{} of {} samples differ".format(off_seen, 16 * n_checked)
     assert n_checked >= 290
 
 

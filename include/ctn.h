@@ -200,6 +200,26 @@ int ctn_lstm_fwd(const float* xproj, const float* whh, int N, int T, int H, int 
 int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N, int T, int H, int D, float* dgates,
                  float* dbias, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense products over feature-last rows: the input projection of the dual-path blocks' LSTMs (nn.LSTM's W_ih x_t + b_ih +
+ * b_hh, src/models/dprnn.py:60-64,85 inside chunks, :104-114,137 across chunks), their linear layers (nn.Linear,
+ * dprnn.py:62,87 and :116,139) and the weight / input gradients of both.  X, Y, dY are (R, features) fp32 row-major
+ * with row strides ldx / ldy / lddy (in floats; views with a column offset are fine), R = sequences x steps.
+ *   ctn_rows_gemm   Y[r][m] = sum_k X[r][k] * Wkm (+ bias[m]);  w_is_km = 0: W is (M, K) row-major, torch's (out, in)
+ *                   layout, i.e. Y = X W^T + b (forward);  w_is_km = 1: W is (K, M) row-major, i.e. Y = X W (the input
+ *                   gradient dX = dY W with the forward weight as it lies).  bias may be null.
+ *   ctn_rows_wgrad  dW[m][k] += sign * sum_r dY[r][m] * X[r][k] and, when dbias is not null,
+ *                   dbias[m] += sign * sum_r dY[r][m]; dW (M, K) with row stride lddw and dbias are accumulated into
+ *                   with float atomics (the caller zeroes them; summation order varies from run to run).  sign = -1
+ *                   subtracts a product (the sequence-boundary terms of a shifted product).
+ * Products on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).  Any R, K, M >= 1; 16-byte aligned bases
+ * and row strides that are multiples of 4 floats take the vector-load path, anything else a scalar one.
+ * ------------------------------------------------------------------------------------------- */
+int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_is_km, const float* bias, int64_t R,
+                  int K, int M, float* Y, int64_t ldy, void* stream);
+int ctn_rows_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t R, int M, int K, float* dW,
+                   int64_t lddw, float* dbias, float sign, void* stream);
+
 /* Finishing a global layer norm's reduction inside the launch that produces its sums (field `fin` of the argument structs
  * below; it applies to that launch's `esums` / `isums`).  With `count` given, the block that adds the LAST partial sums
  * of a batch element also turns the element's sums into the two scalars the consumers read, so no launch of

@@ -1,0 +1,267 @@
+// Dense products over feature-last rows on the f32 MFMA, gfx950: the input projection of the dual-path blocks' LSTMs,
+// their linear layers and every weight / input gradient of both (src/models/dprnn.py:60-64,85-88 inside chunks,
+// :104-116,137-140 across chunks of the reference: nn.LSTM's W_ih x_t + b, nn.Linear, and their backward passes).
+//
+// The recurrences keep their tensors as (sequence, step) rows with the features contiguous -- R = sequences x steps rows,
+// 205 200 of them at the recipe's size, against 64 to 1024 features -- so the two products have their own shapes:
+//
+//   rows_gemm   Y[r][m]  = sum_k X[r][k] * W(k, m) (+ bias[m])       tall output, short contraction; the output write is
+//                                                                    what it costs (R x M floats)
+//   rows_wgrad  dW[m][k] += sign * sum_r dY[r][m] * X[r][k]          small output, contraction over ALL rows: split over row
+//                                                                    chunks (one generation of resident blocks), every block
+//                                                                    ends with float atomics of its tile; optional column
+//                                                                    sums of dY (the bias gradient) on the way
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32, i.e. exact fp32 products accumulated in fp32.  Both kernels are bound by their
+// operand / result streams at these shapes (the projection of one LSTM: 27 GFLOP against 0.9 GB), so the f32 matrix
+// instruction's rate is not what limits them.
+//
+// In rows_wgrad the contraction index is the ROW index of both operands, so the MFMA fragments (one value per lane:
+// A[m = lane % 32][kk = lane / 32], B[kk][n = lane % 32]) are plain conflict-free reads of row-major LDS tiles.
+// rows_gemm contracts along the rows' contiguous axis: its X tile is staged k-major in LDS.
+#include "ctn_common.h"
+
+namespace {
+
+constexpr int RNTH = 256;
+
+// four consecutive floats of row `p` starting at column c of a row with `ncols` valid columns; zero beyond the row
+// (vec: p + c is 16-byte aligned and c + 3 < ncols is decided by the caller's layout: row pitch and base multiples of 4)
+__device__ __forceinline__ f32x4 rows_ld4(const float* __restrict__ p, const int c, const int ncols, const bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec && c + 3 < ncols) return ctn_ld4(p + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c + e < ncols) v[e] = p[c + e];
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ Y = X W (+ b)
+// Block: 128 rows x 128 output columns, four waves of 32 rows x 128 columns (4 accumulator tiles); contraction in
+// chunks of 32.  X tile k-major in LDS (Xs[k][row], pitch 132: a fragment read takes 32 consecutive rows of one k).
+// W tile: W_KM (W stored [K][M], the product with the transposed forward weight) lands as it lies, Ws[k][m];
+// otherwise (W stored [M][K], torch's (out, in) layout) it is staged k-major like X.
+template <bool W_KM>
+__global__ __launch_bounds__(RNTH) void rows_gemm_kernel(const float* __restrict__ X, const int64_t ldx,
+                                                         const float* __restrict__ W, const int64_t ldw,
+                                                         const float* __restrict__ bias, const int64_t R, const int K,
+                                                         const int M, float* __restrict__ Y, const int64_t ldy,
+                                                         const bool xvec, const bool wvec) {
+    constexpr int BR = 128, BM = 128, KC = 32, PITCH = 132;
+    __shared__ __attribute__((aligned(16))) float Xs[KC * PITCH];
+    __shared__ __attribute__((aligned(16))) float Ws[KC * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * BR;
+    const int m0 = blockIdx.y * BM;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // loaders: a 128 x 32 tile is 1024 float4, four per thread; thread -> (row = tid / 8 + 32 q, 4 columns at (tid % 8) * 4)
+    const int lc = (tid & 7) * 4, lr = tid >> 3;
+    f32x4 rx[4], rw[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t r = r0 + lr + 32 * q;
+            rx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < R) rx[q] = rows_ld4(X + r * ldx + k0, lc, K - k0, xvec);
+            if (W_KM) {      // rows of W are contraction indices: tile rows k0 + (tid / 32 + 8 q), columns m0 + (tid % 32) * 4
+                const int kk = k0 + (tid >> 5) + 8 * q;
+                rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kk < K) rw[q] = rows_ld4(W + (int64_t)kk * ldw + m0, (tid & 31) * 4, M - m0, wvec);
+            } else {
+                const int m = m0 + lr + 32 * q;
+                rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M) rw[q] = rows_ld4(W + (int64_t)m * ldw + k0, lc, K - k0, wvec);
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Xs[(lc + e) * PITCH + lr + 32 * q] = rx[q][e];
+            if (W_KM) {
+                ctn_st4(&Ws[((tid >> 5) + 8 * q) * PITCH + (tid & 31) * 4], rw[q]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Ws[(lc + e) * PITCH + lr + 32 * q] = rw[q][e];
+            }
+        }
+    };
+
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        stage();
+        __syncthreads();
+        if (k0 + KC < K) fetch(k0 + KC);
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const int kk = 2 * s + half;
+            const float av = Xs[kk * PITCH + wave * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bv = Ws[kk * PITCH + j * 32 + l31];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // accumulators -> Y: register e of lane (l31, half) is row (e & 3) + 8 (e >> 2) + 4 half, column l31 of its tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + j * 32 + l31;
+        if (m >= M) continue;
+        const float bj = bias ? bias[m] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t r = r0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (r < R) Y[r * ldy + m] = acc[j][e] + bj;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dW += dY^T X
+// Block: TM x 64 output tile and one chunk of rows; stages of 32 rows: dYs[32][TM], Xs[32][64] row-major as they lie in
+// memory.  TM = 128: wave w owns output rows 32 w .. 32 w + 31 and both 32-column tiles; TM = 64: wave w owns row tile
+// w / 2 and column tile w % 2.  Blocks of column tile 0 also sum dY's columns (the bias gradient).
+template <int TM>
+__global__ __launch_bounds__(RNTH) void rows_wgrad_kernel(const float* __restrict__ dY, const int64_t lddy,
+                                                          const float* __restrict__ X, const int64_t ldx, const int64_t R,
+                                                          const int M, const int K, float* __restrict__ dW,
+                                                          const int64_t lddw, float* __restrict__ dbias, const float sign,
+                                                          const int64_t rchunk, const bool yvec, const bool xvec) {
+    constexpr int TK = 64, RS = 32;
+    constexpr int NY = TM * RS / 4 / RNTH;       // float4 per thread per stage: 4 (TM = 128) or 2
+    constexpr int NX = TK * RS / 4 / RNTH;       // 2
+    constexpr int TJ = TM == 128 ? 2 : 1;        // column tiles per wave
+    __shared__ __attribute__((aligned(16))) float Ys[RS * TM];
+    __shared__ __attribute__((aligned(16))) float Xs[RS * TK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TK;
+    const int64_t rb = (int64_t)blockIdx.z * rchunk, re = rb + rchunk < R ? rb + rchunk : R;
+    const int wm = TM == 128 ? wave * 32 : (wave >> 1) * 32;
+    const int wk = TM == 128 ? 0 : (wave & 1) * 32;
+
+    f32x16 acc[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float colsum = 0.f;
+    const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+
+    constexpr int YC = TM / 4;                   // float4 per tile row of dY
+    f32x4 ry[NY], rx[NX];
+    auto fetch = [&](int64_t r_stage) {
+#pragma unroll
+        for (int q = 0; q < NY; ++q) {
+            const int i = tid + RNTH * q;
+            const int64_t r = r_stage + i / YC;
+            ry[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < re) ry[q] = rows_ld4(dY + r * lddy + m0, (i % YC) * 4, M - m0, yvec);
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int i = tid + RNTH * q;
+            const int64_t r = r_stage + i / (TK / 4);
+            rx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < re) rx[q] = rows_ld4(X + r * ldx + k0, (i % (TK / 4)) * 4, K - k0, xvec);
+        }
+    };
+
+    if (rb < re) {
+        fetch(rb);
+        for (int64_t rs = rb; rs < re; rs += RS) {
+#pragma unroll
+            for (int q = 0; q < NY; ++q) ctn_st4(&Ys[(tid + RNTH * q) * 4], ry[q]);
+#pragma unroll
+            for (int q = 0; q < NX; ++q) ctn_st4(&Xs[(tid + RNTH * q) * 4], rx[q]);
+            __syncthreads();
+            if (rs + RS < re) fetch(rs + RS);
+#pragma unroll
+            for (int s = 0; s < RS / 2; ++s) {
+                const int rr = 2 * s + half;
+                const float av = Ys[rr * TM + wm + l31];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const float bv = Xs[rr * TK + wk + j * 32 + l31];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+                }
+            }
+            if (do_bias && tid < TM) {
+#pragma unroll 8
+                for (int rr = 0; rr < RS; ++rr) colsum += Ys[rr * TM + tid];
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int k = k0 + wk + j * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (m < M && k < K) atomicAdd(dW + (int64_t)m * lddw + k, sign * acc[j][e]);
+        }
+    }
+    if (do_bias && tid < TM && m0 + tid < M) atomicAdd(dbias + m0 + tid, sign * colsum);
+}
+
+}  // namespace
+
+extern "C" int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_is_km, const float* bias,
+                             int64_t R, int K, int M, float* Y, int64_t ldy, void* stream) {
+    CTN_REQUIRE(X && W && Y, "ctn_rows_gemm: null pointer");
+    CTN_REQUIRE(R > 0 && K > 0 && M > 0, "ctn_rows_gemm: empty shape");
+    CTN_REQUIRE(ldx >= K && ldy >= M && ldw >= (w_is_km ? M : K), "ctn_rows_gemm: a row stride shorter than the row");
+    CTN_REQUIRE((R + 127) / 128 <= 0x7fffffff && ctn_cdiv(M, 128) <= 65535, "ctn_rows_gemm: too many tiles");
+    const bool xvec = ctn_aligned16(X) && ldx % 4 == 0;
+    const bool wvec = ctn_aligned16(W) && ldw % 4 == 0;
+    dim3 grid((unsigned)((R + 127) / 128), ctn_cdiv(M, 128));
+    if (w_is_km)
+        hipLaunchKernelGGL(rows_gemm_kernel<true>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
+                           Y, ldy, xvec, wvec);
+    else
+        hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
+                           Y, ldy, xvec, wvec);
+    CTN_CHECK_LAUNCH("ctn_rows_gemm");
+    return CTN_OK;
+}
+
+extern "C" int ctn_rows_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t R, int M, int K,
+                              float* dW, int64_t lddw, float* dbias, float sign, void* stream) {
+    CTN_REQUIRE(dY && X && dW, "ctn_rows_wgrad: null pointer");
+    CTN_REQUIRE(R > 0 && K > 0 && M > 0, "ctn_rows_wgrad: empty shape");
+    CTN_REQUIRE(lddy >= M && ldx >= K && lddw >= K, "ctn_rows_wgrad: a row stride shorter than the row");
+    const bool yvec = ctn_aligned16(dY) && lddy % 4 == 0;
+    const bool xvec = ctn_aligned16(X) && ldx % 4 == 0;
+    const int TM = M > 64 ? 128 : 64;
+    const int tiles = ctn_cdiv(M, TM) * ctn_cdiv(K, 64);
+    CTN_REQUIRE(ctn_cdiv(K, 64) <= 65535, "ctn_rows_wgrad: too many column tiles");
+    // one generation of resident blocks (about four per CU), chunks of whole 32-row stages, at least 256 rows each
+    int64_t nchunks = 1024 / tiles;
+    if (nchunks < 1) nchunks = 1;
+    int64_t rchunk = (R + nchunks - 1) / nchunks;
+    rchunk = (rchunk + 31) / 32 * 32;
+    if (rchunk < 256) rchunk = 256;
+    nchunks = (R + rchunk - 1) / rchunk;
+    CTN_REQUIRE(nchunks <= 65535, "ctn_rows_wgrad: too many row chunks");
+    dim3 grid(ctn_cdiv(M, TM), ctn_cdiv(K, 64), (unsigned)nchunks);
+    if (TM == 128)
+        hipLaunchKernelGGL(rows_wgrad_kernel<128>, grid, dim3(RNTH), 0, (hipStream_t)stream, dY, lddy, X, ldx, R, M, K, dW,
+                           lddw, dbias, sign, rchunk, yvec, xvec);
+    else
+        hipLaunchKernelGGL(rows_wgrad_kernel<64>, grid, dim3(RNTH), 0, (hipStream_t)stream, dY, lddy, X, ldx, R, M, K, dW,
+                           lddw, dbias, sign, rchunk, yvec, xvec);
+    CTN_CHECK_LAUNCH("ctn_rows_wgrad");
+    return CTN_OK;
+}

@@ -484,44 +484,36 @@ class LayerNormFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ recurrence
-def reduce_matmul(a, b):
-    """a (R, M), b (R, N), rows uniformly strided -> a^T b (M, N) for R in the hundreds of thousands (every (sequence,
-    step) pair of a recurrent layer).  As one product the GEMM library runs it on M*N / tile workgroups -- 16 for a
-    512 x 128 weight gradient, on 256 CUs -- so the reduction is cut into batched partial products that are added."""
-    R = a.shape[0]
-    C = max(1, min(256, R // 1024))
-    per = R // C
-    main = per * C
-    out = torch.bmm(a[:main].view(C, per, a.shape[1]).transpose(1, 2), b[:main].view(C, per, b.shape[1])).sum(dim=0)
-    if main < R:
-        out = out + a[main:].t() @ b[main:]
-    return out
-
-
 class LinearFn(torch.autograd.Function):
-    """nn.Linear over (rows, features) with the weight gradient as a split reduction (reduce_matmul)."""
+    """nn.Linear over (rows, features) (src/models/dprnn.py:62,87 and :116,139) on the row-product kernels: forward and
+    input gradient are ctn_rows_gemm, weight and bias gradient one ctn_rows_wgrad over all rows."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        ops._require_cuda(x, weight)
         shape = x.shape
-        x2 = x.detach().reshape(-1, shape[-1])
-        ctx.saved = (x2, weight, bias is not None, shape)
-        y = torch.addmm(bias.detach(), x2, weight.detach().t()) if bias is not None else x2 @ weight.detach().t()
+        x2 = x.detach().reshape(-1, shape[-1]).float()
+        w = weight.detach().float()
+        ctx.saved = (x2, w, bias is not None, shape)
+        y = ops.rows_gemm(x2, w, None if bias is None else bias.detach().float().contiguous())
         return y.view(shape[:-1] + (weight.shape[0],))
 
     @staticmethod
     def backward(ctx, dy):
-        x2, weight, has_bias, shape = ctx.saved
-        dy2 = dy.reshape(-1, weight.shape[0])
-        dx = (dy2 @ weight.detach()).view(shape) if ctx.needs_input_grad[0] else None
-        return dx, reduce_matmul(dy2, x2), dy2.sum(dim=0) if has_bias else None
+        x2, w, has_bias, shape = ctx.saved
+        dy2 = dy.reshape(-1, w.shape[0]).float()
+        dx = ops.rows_gemm(dy2, w, w_is_km=True).view(shape) if ctx.needs_input_grad[0] else None
+        db = torch.zeros((w.shape[0],), device=dy2.device, dtype=torch.float32) if has_bias else None
+        dW = ops.rows_wgrad(dy2, x2, dbias=db)
+        return dx, dW, db
 
 
 class LstmFn(torch.autograd.Function):
-    """nn.LSTM(batch_first=True, num_layers=1), one or two directions, zero initial state, on the persistent recurrence
-    kernels: x (N, T, F) -> (N, T, D*H).  The input projection of all steps is one GEMM in front of the recurrence
-    (torch.addmm, i.e. the GEMM library), the recurrence itself and its backward pass through time are ctn_lstm_fwd /
-    ctn_lstm_bwd, and the parameter / input gradients are GEMMs over all (sequence, step) pairs behind it.
+    """nn.LSTM(batch_first=True, num_layers=1), one or two directions, zero initial state: x (N, T, F) -> (N, T, D*H) and
+    the final states.  The input projection of all steps is one ctn_rows_gemm in front of the recurrence, the
+    recurrence itself and its backward pass through time are ctn_lstm_fwd / ctn_lstm_bwd (one launch per walk), and
+    the parameter / input gradients are row products over all (sequence, step) pairs behind it (ctn_rows_wgrad /
+    ctn_rows_gemm): no launch of a GEMM library anywhere.
     params: weight_ih, weight_hh, bias_ih, bias_hh per direction, in nn.LSTM's _flat_weights order."""
 
     @staticmethod
@@ -534,7 +526,7 @@ class LstmFn(torch.autograd.Function):
         H = w_hh[0].shape[1]
         x2 = x.detach().reshape(N * T, F_in).float()
         w_ih_all = torch.cat(w_ih, dim=0)                                  # (D*4H, F)
-        xproj = torch.addmm(torch.cat(bias), x2, w_ih_all.t()).view(N, T, n_dir, 4 * H)
+        xproj = ops.rows_gemm(x2, w_ih_all, torch.cat(bias)).view(N, T, n_dir, 4 * H)
         whh = torch.stack(w_hh).contiguous()                              # (D, 4H, H)
         hout, save = ops.lstm_fwd(xproj, whh)
         ctx.saved = (x2, w_ih_all, whh, hout, save, n_dir, (N, T, F_in, H))
@@ -552,26 +544,27 @@ class LstmFn(torch.autograd.Function):
         dgates, db_all = ops.lstm_bwd(dout.contiguous().float().view(N, T, n_dir, H), save, whh)      # (N, T, D, 4H), (D, 4H)
         db_all = db_all.view(-1)
         dg2 = dgates.view(N * T, n_dir * 4 * H)
-        dx = (dg2 @ w_ih_all).view(N, T, F_in) if ctx.needs_input_grad[0] else None
-        dw_ih_all = reduce_matmul(dg2, x2)                                # (D*4H, F)
+        dx = ops.rows_gemm(dg2, w_ih_all, w_is_km=True).view(N, T, F_in) if ctx.needs_input_grad[0] else None
+        dw_ih_all = ops.rows_wgrad(dg2, x2)                               # (D*4H, F)
         # recurrent weights: sum over (n, t) of dgates[n, t]^T h[n, t -+ 1], h of the step before t in the direction's own
         # order.  Over the flat (n, t) index that is one shifted product of the whole tensors, minus the N - 1 terms that
-        # pair the first step of a sequence with the last state of its neighbour (no shifted copy of h is made).
+        # pair the first step of a sequence with the last state of its neighbour (no shifted copy of h is made): both are
+        # row products over strided views, the second one subtracted into the same tensor.
         dg3 = dgates.view(N * T, n_dir, 4 * H)
         h3 = hout.view(N * T, n_dir, H)
         grads = []
         for d in range(n_dir):
             dg, h = dg3[:, d], h3[:, d]                                   # (N*T, 4H), (N*T, H): strided views
-            if N * T < 2:
-                dw_hh = torch.zeros((4 * H, H), device=hout.device, dtype=torch.float32)
-            elif d == 0:
-                dw_hh = reduce_matmul(dg[1:], h[:-1])
-                if N > 1:
-                    dw_hh = dw_hh - dgates[1:, 0, d].t() @ hout[:-1, T - 1, d]
-            else:
-                dw_hh = reduce_matmul(dg[:-1], h[1:])
-                if N > 1:
-                    dw_hh = dw_hh - dgates[:-1, T - 1, d].t() @ hout[1:, 0, d]
+            dw_hh = torch.zeros((4 * H, H), device=hout.device, dtype=torch.float32)
+            if N * T >= 2:
+                if d == 0:
+                    ops.rows_wgrad(dg[1:], h[:-1], dW=dw_hh)
+                    if N > 1:
+                        ops.rows_wgrad(dgates[1:, 0, d], hout[:-1, T - 1, d], dW=dw_hh, sign=-1.0)
+                else:
+                    ops.rows_wgrad(dg[:-1], h[1:], dW=dw_hh)
+                    if N > 1:
+                        ops.rows_wgrad(dgates[:-1, T - 1, d], hout[1:, 0, d], dW=dw_hh, sign=-1.0)
             db = db_all[d * 4 * H:(d + 1) * 4 * H]
             grads += [dw_ih_all[d * 4 * H:(d + 1) * 4 * H], dw_hh, db, db]
         return (dx, None) + tuple(grads)

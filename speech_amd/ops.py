@@ -296,6 +296,61 @@ def lstm_bwd(dhout, save, whh, bias_grad=True):
     return dgates, dbias
 
 
+# ------------------------------------------------------------------------------------------------ products over rows
+def _rows2d(t):
+    """A (rows, features) fp32 view with unit feature stride (row stride arbitrary), or a contiguous copy of it."""
+    _require_cuda(t)
+    assert t.dim() == 2 and t.dtype == torch.float32
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def rows_gemm(x, w, bias=None, w_is_km=False):
+    """x (R, K) rows -> y (R, M) = x w^T + bias for w (M, K) (w_is_km False: nn.Linear's layout), or x w for w (K, M)
+    (w_is_km True: the input gradient of such a layer, the weight as it lies); see ctn_rows_gemm."""
+    lib = _lib.load()
+    x, w = _rows2d(x), _rows2d(w)
+    R, K = x.shape
+    M = w.shape[1] if w_is_km else w.shape[0]
+    assert (w.shape[0] if w_is_km else w.shape[1]) == K
+    y = torch.empty((R, M), device=x.device, dtype=torch.float32)
+    if R == 0:
+        return y
+    if bias is not None:
+        _require_cuda(bias)
+        assert bias.dtype == torch.float32 and bias.numel() == M and bias.is_contiguous()
+    _lib.check(lib.ctn_rows_gemm(_ptr(x), _ld(x), _ptr(w), _ld(w), 1 if w_is_km else 0, _ptr(bias), R, K, M, _ptr(y), M,
+                                 _stream()), "ctn_rows_gemm")
+    return y
+
+
+def rows_wgrad(dy, x, dW=None, dbias=None, sign=1.0):
+    """dW (M, K) += sign * dy^T x over the rows of dy (R, M) and x (R, K); dbias (M,) += sign * column sums of dy when
+    given.  dW None: a zeroed (M, K) tensor is made and returned; see ctn_rows_wgrad."""
+    lib = _lib.load()
+    dy, x = _rows2d(dy), _rows2d(x)
+    R, M = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == R
+    if dW is None:
+        dW = torch.zeros((M, K), device=dy.device, dtype=torch.float32)
+    assert dW.dtype == torch.float32 and tuple(dW.shape) == (M, K) and (K == 1 or dW.stride(1) == 1)
+    if dbias is not None:
+        assert dbias.dtype == torch.float32 and dbias.numel() == M and dbias.is_contiguous()
+    if R == 0:
+        return dW
+    _lib.check(lib.ctn_rows_wgrad(_ptr(dy), _ld(dy), _ptr(x), _ld(x), R, M, K, _ptr(dW), _ld(dW), _ptr(dbias), float(sign),
+                                  _stream()), "ctn_rows_wgrad")
+    return dW
+
+
 # ------------------------------------------------------------------------------------------------ axis shuffles
 def _reaches(t, last):
     """True if element offset `last` (from t's first element) lies inside t's storage."""

@@ -46,14 +46,15 @@ __global__ __launch_bounds__(RNTH) void rows_gemm_kernel(const float* __restrict
                                                          const float* __restrict__ W, const int64_t ldw,
                                                          const float* __restrict__ bias, const int64_t R, const int K,
                                                          const int M, float* __restrict__ Y, const int64_t ldy,
-                                                         const bool xvec, const bool wvec) {
+                                                         const bool xvec, const bool wvec, const unsigned tiles_m) {
     constexpr int BR = 128, BM = 128, KC = 32, PITCH = 132;
     __shared__ __attribute__((aligned(16))) float Xs[KC * PITCH];
     __shared__ __attribute__((aligned(16))) float Ws[KC * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int64_t r0 = (int64_t)blockIdx.x * BR;
-    const int m0 = blockIdx.y * BM;
+    // column tile fastest: the blocks in flight together write whole rows of Y (every memory channel) and share X tiles
+    const int64_t r0 = (int64_t)(blockIdx.x / tiles_m) * BR;
+    const int m0 = (int)(blockIdx.x % tiles_m) * BM;
 
     f32x16 acc[4];
 #pragma unroll
@@ -123,6 +124,154 @@ __global__ __launch_bounds__(RNTH) void rows_gemm_kernel(const float* __restrict
         for (int e = 0; e < 16; ++e) {
             const int64_t r = r0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
             if (r < R) Y[r * ldy + m] = acc[j][e] + bj;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Y = X W^T (+ b), six bf16 products
+// The same product in the exact three-piece arithmetic of the pointwise GEMMs (CTN_ARITH_BF16X3): every fp32 element of
+// both tiles is split ONCE, by the thread that stages it, into three bf16 pieces (hi + mid + lo = x exactly, eight
+// significant bits each), written to three LDS planes [row][k] of bf16 -- both operands are contiguous along the
+// contraction, which is the matrix instruction's fragment order, so a fragment is one 16-byte LDS read per plane -- and
+// the product tile is hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (what is dropped is
+// below one fp32 rounding of the product).  Six bf16 instructions cost 6/16 of one f32 instruction's time for the same
+// product, which takes these launches from the matrix unit's roof to the memory roof.  Rows of 40 bf16 (80 bytes): the
+// 16 lanes the LDS serves together for a 16-byte read then cover all 64 banks.  The result leaves through LDS, half a
+// wave's strip at a time, as 16-byte stores of 256 contiguous bytes per row.
+typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ru32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void rows_split3(const f32x4 v, ru32x2& hi, ru32x2& mid, ru32x2& lo) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a0 = v[2 * i], a1 = v[2 * i + 1];
+        const unsigned x0 = __float_as_uint(a0), x1 = __float_as_uint(a1);
+        hi[i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        const float r0 = a0 - __uint_as_float(x0 & 0xffff0000u), r1 = a1 - __uint_as_float(x1 & 0xffff0000u);
+        const unsigned ru0 = __float_as_uint(r0), ru1 = __float_as_uint(r1);
+        mid[i] = __builtin_amdgcn_perm(ru1, ru0, 0x07060302u);
+        const float q0 = r0 - __uint_as_float(ru0 & 0xffff0000u), q1 = r1 - __uint_as_float(ru1 & 0xffff0000u);
+        lo[i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    }
+}
+
+__global__ __launch_bounds__(RNTH) void rows_gemm_b3_kernel(const float* __restrict__ X, const int64_t ldx,
+                                                            const float* __restrict__ W, const int64_t ldw,
+                                                            const float* __restrict__ bias, const int64_t R, const int K,
+                                                            const int M, float* __restrict__ Y, const int64_t ldy,
+                                                            const bool xvec, const bool wvec, const bool yvec,
+                                                            const unsigned tiles_m) {
+    constexpr int BR = 128, BM = 128, KC = 32, PB = 40;       // PB: bf16 per LDS row (32 + 8 of padding)
+    constexpr int PLANE = BR * PB;                            // bf16 per plane
+    __shared__ __attribute__((aligned(16))) __bf16 planes[6 * PLANE];
+    __bf16* const Xp = planes;
+    __bf16* const Wp = planes + 3 * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    // column tile fastest: the blocks in flight together write whole rows of Y (every memory channel) and share X tiles
+    const int64_t r0 = (int64_t)(blockIdx.x / tiles_m) * BR;
+    const int m0 = (int)(blockIdx.x % tiles_m) * BM;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    const int lc = (tid & 7) * 4, lr = tid >> 3;     // thread -> (row lr + 32 q, 4 contraction indices at lc)
+    f32x4 rx[4], rw[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t r = r0 + lr + 32 * q;
+            const int m = m0 + lr + 32 * q;
+            rx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < R) rx[q] = rows_ld4(X + r * ldx + k0, lc, K - k0, xvec);
+            if (m < M) rw[q] = rows_ld4(W + (int64_t)m * ldw + k0, lc, K - k0, wvec);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = (lr + 32 * q) * PB + lc;
+            ru32x2 h, m, l;
+            rows_split3(rx[q], h, m, l);
+            *reinterpret_cast<ru32x2*>(&Xp[o]) = h;
+            *reinterpret_cast<ru32x2*>(&Xp[PLANE + o]) = m;
+            *reinterpret_cast<ru32x2*>(&Xp[2 * PLANE + o]) = l;
+            rows_split3(rw[q], h, m, l);
+            *reinterpret_cast<ru32x2*>(&Wp[o]) = h;
+            *reinterpret_cast<ru32x2*>(&Wp[PLANE + o]) = m;
+            *reinterpret_cast<ru32x2*>(&Wp[2 * PLANE + o]) = l;
+        }
+    };
+
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        stage();
+        __syncthreads();
+        if (k0 + KC < K) fetch(k0 + KC);
+#pragma unroll
+        for (int s = 0; s < KC / 16; ++s) {
+            const int ao = (wave * 32 + l31) * PB + 16 * s + 8 * half;
+            const rbf16x8 ah = *reinterpret_cast<const rbf16x8*>(&Xp[ao]);
+            const rbf16x8 am = *reinterpret_cast<const rbf16x8*>(&Xp[PLANE + ao]);
+            const rbf16x8 al = *reinterpret_cast<const rbf16x8*>(&Xp[2 * PLANE + ao]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bo = (j * 32 + l31) * PB + 16 * s + 8 * half;
+                const rbf16x8 bh = *reinterpret_cast<const rbf16x8*>(&Wp[bo]);
+                const rbf16x8 bm = *reinterpret_cast<const rbf16x8*>(&Wp[PLANE + bo]);
+                const rbf16x8 bl = *reinterpret_cast<const rbf16x8*>(&Wp[2 * PLANE + bo]);
+                // smallest terms first
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // accumulators -> Y through LDS (the operand planes are free behind the loop's last barrier): each wave owns 8 KB,
+    // a 32-row x 64-column half of its strip at a time, rows of 68 floats; then every lane stores 16 bytes, 16 lanes a row.
+    float* out = reinterpret_cast<float*>(planes) + wave * (32 * 68);
+    static_assert(4 * 32 * 68 * 4 <= 6 * PLANE * 2, "epilogue staging fits the operand planes");
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * hc + jj;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * half) * 68 + jj * 32 + l31] = acc[j][e];
+        }
+        // (a wave reads back only what it wrote itself: no barrier, the LDS executes a wave's accesses in order)
+        const int c4 = (lane & 15) * 4;                  // 4 columns of the 64
+        const int mcol = m0 + hc * 64 + c4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (mcol + e < M) bv[e] = bias[mcol + e];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = rr * 4 + (lane >> 4);
+            const int64_t r = r0 + wave * 32 + row;
+            f32x4 v = ctn_ld4(&out[row * 68 + c4]);
+            if (r < R) {
+                float* dst = Y + r * ldy + mcol;
+                if (yvec && mcol + 3 < M) {
+                    ctn_st4(dst, v + bv);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (mcol + e < M) dst[e] = v[e] + bv[e];
+                }
+            }
         }
     }
 }
@@ -219,20 +368,27 @@ __global__ __launch_bounds__(RNTH) void rows_wgrad_kernel(const float* __restric
 }  // namespace
 
 extern "C" int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_is_km, const float* bias,
-                             int64_t R, int K, int M, float* Y, int64_t ldy, void* stream) {
+                             int64_t R, int K, int M, float* Y, int64_t ldy, int arith, void* stream) {
     CTN_REQUIRE(X && W && Y, "ctn_rows_gemm: null pointer");
     CTN_REQUIRE(R > 0 && K > 0 && M > 0, "ctn_rows_gemm: empty shape");
     CTN_REQUIRE(ldx >= K && ldy >= M && ldw >= (w_is_km ? M : K), "ctn_rows_gemm: a row stride shorter than the row");
-    CTN_REQUIRE((R + 127) / 128 <= 0x7fffffff && ctn_cdiv(M, 128) <= 65535, "ctn_rows_gemm: too many tiles");
+    const unsigned tiles_m = (unsigned)ctn_cdiv(M, 128);
+    CTN_REQUIRE((R + 127) / 128 * tiles_m <= 0x7fffffff, "ctn_rows_gemm: too many tiles");
+    CTN_REQUIRE(arith == CTN_ARITH_DEFAULT || arith == CTN_ARITH_F32 || arith == CTN_ARITH_BF16X3,
+                "ctn_rows_gemm: arith is CTN_ARITH_DEFAULT, CTN_ARITH_F32 or CTN_ARITH_BF16X3");
     const bool xvec = ctn_aligned16(X) && ldx % 4 == 0;
     const bool wvec = ctn_aligned16(W) && ldw % 4 == 0;
-    dim3 grid((unsigned)((R + 127) / 128), ctn_cdiv(M, 128));
-    if (w_is_km)
+    const bool yvec = ctn_aligned16(Y) && ldy % 4 == 0;
+    dim3 grid((unsigned)((R + 127) / 128 * tiles_m));
+    if (w_is_km)        // the weight's rows are the contraction: f32 matrix instructions (both arithmetic modes)
         hipLaunchKernelGGL(rows_gemm_kernel<true>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
-                           Y, ldy, xvec, wvec);
-    else
+                           Y, ldy, xvec, wvec, tiles_m);
+    else if (arith == CTN_ARITH_F32)
         hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
-                           Y, ldy, xvec, wvec);
+                           Y, ldy, xvec, wvec, tiles_m);
+    else
+        hipLaunchKernelGGL(rows_gemm_b3_kernel, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M, Y,
+                           ldy, xvec, wvec, yvec, tiles_m);
     CTN_CHECK_LAUNCH("ctn_rows_gemm");
     return CTN_OK;
 }

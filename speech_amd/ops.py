@@ -312,11 +312,18 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
-def rows_gemm(x, w, bias=None, w_is_km=False):
+def rows_gemm(x, w, bias=None, w_is_km=False, arith=None):
     """x (R, K) rows -> y (R, M) = x w^T + bias for w (M, K) (w_is_km False: nn.Linear's layout), or x w for w (K, M)
-    (w_is_km True: the input gradient of such a layer, the weight as it lies); see ctn_rows_gemm."""
+    (w_is_km True: the input gradient of such a layer, the weight as it lies); see ctn_rows_gemm.  arith: CTN_ARITH_*
+    (None: this module's current GEMM arithmetic, set_gemm_split).  In the three-piece arithmetic a (K, M) weight -- a
+    small matrix -- is transposed first (ctn_transpose), so that the product takes the bf16 kernel."""
     lib = _lib.load()
     x, w = _rows2d(x), _rows2d(w)
+    arith = (_lib.ARITH_F32 if _gemm_split == 0 else _lib.ARITH_BF16X3) if arith is None else arith
+    if w_is_km and arith != _lib.ARITH_F32:
+        wt = torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=torch.float32)
+        transpose(w.contiguous(), wt, w.shape[0])
+        w, w_is_km = wt, False
     R, K = x.shape
     M = w.shape[1] if w_is_km else w.shape[0]
     assert (w.shape[0] if w_is_km else w.shape[1]) == K
@@ -327,7 +334,7 @@ def rows_gemm(x, w, bias=None, w_is_km=False):
         _require_cuda(bias)
         assert bias.dtype == torch.float32 and bias.numel() == M and bias.is_contiguous()
     _lib.check(lib.ctn_rows_gemm(_ptr(x), _ld(x), _ptr(w), _ld(w), 1 if w_is_km else 0, _ptr(bias), R, K, M, _ptr(y), M,
-                                 _stream()), "ctn_rows_gemm")
+                                 arith, _stream()), "ctn_rows_gemm")
     return y
 
 

@@ -19,16 +19,18 @@ SHAPES = [(1000, 64, 1024), (4100, 256, 64), (777, 1024, 64), (130, 12, 400), (5
 
 @pytest.mark.parametrize("R,K,M", SHAPES)
 @pytest.mark.parametrize("w_is_km", [False, True])
-def test_rows_gemm_matches_float64(R, K, M, w_is_km):
-    from speech_amd import ops
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_rows_gemm_matches_float64(R, K, M, w_is_km, arith):
+    from speech_amd import ops, _lib
+    arith = {"f32": _lib.ARITH_F32, "bf16x3": _lib.ARITH_BF16X3}[arith]
     x = synth.normal((R, K), 1)
     w = synth.normal((K, M) if w_is_km else (M, K), 2)
     b = synth.normal((M,), 3)
     ref = x.double() @ (w.double() if w_is_km else w.double().t()) + b.double()
-    y = ops.rows_gemm(x.to(DEV), w.to(DEV), b.to(DEV), w_is_km=w_is_km)
+    y = ops.rows_gemm(x.to(DEV), w.to(DEV), b.to(DEV), w_is_km=w_is_km, arith=arith)
     torch.cuda.synchronize()
     assert_close(y, ref, TOL, "y")
-    y0 = ops.rows_gemm(x.to(DEV), w.to(DEV), None, w_is_km=w_is_km)
+    y0 = ops.rows_gemm(x.to(DEV), w.to(DEV), None, w_is_km=w_is_km, arith=arith)
     assert_close(y0, ref - b.double(), TOL, "y without bias")
 
 

@@ -111,6 +111,9 @@ int ctn_sizeof_dw_bwd_args(void);
  * ctn_probe_mfma_f32: `blocks` blocks of four waves each issue iters x 4 v_mfma_f32_32x32x2_f32 back to back on operands
  *   held in registers (read once from in[0..65535]); out receives blocks*256 floats.  FLOPs = blocks*4*iters*4*4096. */
 int ctn_probe_copy(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* y = a with plain (temporal) 16-byte accesses, 16 KiB chunks in ascending (reverse = 0) or descending block order: measures
+ * what reading a producer's output last-written-first gains from the die-level cache. */
+int ctn_probe_stream(const float* a, float* y, int64_t n, int reverse, void* stream);
 int ctn_probe_mfma_f32(const float* in, float* out, int blocks, int iters, void* stream);
 /* the same with v_mfma_f32_32x32x16_bf16 on bf16 bit patterns drawn from `in`: FLOPs = blocks*4*iters*4*32768 */
 int ctn_probe_mfma_bf16(const float* in, float* out, int blocks, int iters, void* stream);

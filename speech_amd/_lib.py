@@ -144,6 +144,7 @@ PROTOTYPES = {
     "ctn_sizeof_dw_fwd_args": (C.c_int, []),
     "ctn_sizeof_dw_bwd_args": (C.c_int, []),
     "ctn_probe_copy": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "ctn_probe_stream": (C.c_int, [_p, _p, _i64, C.c_int, _p]),
     "ctn_probe_mfma_f32": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "ctn_probe_mfma_bf16": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "ctn_transpose": (C.c_int, [_p, C.c_int, C.c_int, _p, _i64, _i64, _p]),

@@ -20,6 +20,21 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const f32x4* __restrict
         if (base + u * 256 < n4) __builtin_nontemporal_store(v[u], y + base + u * 256);
 }
 
+// Plain (temporal) 16-byte copy, one block per contiguous 16 KiB chunk, chunks taken in ascending or descending address
+// order by block index: what a consumer gains from reading a producer's output last-written-first (the die-level cache
+// holds the most recently touched 256 MiB).
+__global__ __launch_bounds__(256) void probe_stream_kernel(const f32x4* __restrict__ a, f32x4* __restrict__ y, int64_t n4,
+                                                           const int reverse) {
+    const int64_t blk = reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
+    const int64_t base = blk * 1024 + threadIdx.x;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = a[base + u * 256 < n4 ? base + u * 256 : n4 - 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n4) y[base + u * 256] = v[u];
+}
+
 __global__ __launch_bounds__(256) void probe_2r1w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
                                                          f32x4* __restrict__ y, int64_t n4) {
     const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -99,6 +114,17 @@ int ctn_probe_copy(const float* a, const float* b, float* y, int64_t n, void* st
         hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a, (f32x4*)y,
                            n / 4);
     CTN_CHECK_LAUNCH("ctn_probe_copy");
+    return CTN_OK;
+}
+
+int ctn_probe_stream(const float* a, float* y, int64_t n, int reverse, void* stream) {
+    CTN_REQUIRE(a && y && n > 0 && n % 4 == 0 && ctn_aligned16(a) && ctn_aligned16(y),
+                "ctn_probe_stream: needs 16-byte aligned buffers and n %% 4 == 0");
+    CTN_REQUIRE(n / 4 <= (int64_t)1024 * 0x7fffffff, "ctn_probe_stream: n too large");
+    const unsigned blocks = (unsigned)((n / 4 + 1023) / 1024);
+    hipLaunchKernelGGL(probe_stream_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a, (f32x4*)y,
+                       n / 4, reverse);
+    CTN_CHECK_LAUNCH("ctn_probe_stream");
     return CTN_OK;
 }
 

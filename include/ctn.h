@@ -215,17 +215,18 @@ int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N,
  *                   dbias[m] += sign * sum_r dY[r][m]; dW (M, K) with row stride lddw and dbias are accumulated into
  *                   with float atomics (the caller zeroes them; summation order varies from run to run).  sign = -1
  *                   subtracts a product (the sequence-boundary terms of a shifted product).
- * arith (ctn_rows_gemm): CTN_ARITH_DEFAULT / CTN_ARITH_BF16X3 = the exact three-piece split with six bf16 matrix
- * instructions per product, as in ctn_gemm_nn (applies to w_is_km = 0: both operands contiguous along the contraction;
- * a caller that wants it for a (K, M) weight passes the transposed copy); CTN_ARITH_F32 = v_mfma_f32_32x32x2_f32.
- * ctn_rows_wgrad and w_is_km = 1 always use the f32 matrix instruction (exact fp32 products, fp32 accumulation).
+ * arith: CTN_ARITH_DEFAULT / CTN_ARITH_BF16X3 = the exact three-piece split with six bf16 matrix instructions per
+ * product, as in ctn_gemm_nn; CTN_ARITH_F32 = v_mfma_f32_32x32x2_f32.  In ctn_rows_gemm the split form applies to
+ * w_is_km = 0 (both operands contiguous along the contraction; a caller that wants it for a (K, M) weight passes the
+ * transposed copy) and w_is_km = 1 always runs f32 instructions; ctn_rows_wgrad runs f32 instructions by default
+ * (CTN_ARITH_DEFAULT: the faster form at these shapes) and the split form on explicit CTN_ARITH_BF16X3 for M > 64.
  * Any R, K, M >= 1; 16-byte aligned bases and row strides that are multiples of 4 floats take the vector-load path,
  * anything else a scalar one.
  * ------------------------------------------------------------------------------------------- */
 int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_is_km, const float* bias, int64_t R,
                   int K, int M, float* Y, int64_t ldy, int arith, void* stream);
 int ctn_rows_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t R, int M, int K, float* dW,
-                   int64_t lddw, float* dbias, float sign, void* stream);
+                   int64_t lddw, float* dbias, float sign, int arith, void* stream);
 
 /* Finishing a global layer norm's reduction inside the launch that produces its sums (field `fin` of the argument structs
  * below; it applies to that launch's `esums` / `isums`).  With `count` given, the block that adds the LAST partial sums

@@ -157,7 +157,7 @@ PROTOTYPES = {
     "ctn_segment": (C.c_int, [_p, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "ctn_overlap_add": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _i64, _i64, _p]),
     "ctn_rows_gemm": (C.c_int, [_p, _i64, _p, _i64, C.c_int, _p, _i64, C.c_int, C.c_int, _p, _i64, C.c_int, _p]),
-    "ctn_rows_wgrad": (C.c_int, [_p, _i64, _p, _i64, _i64, C.c_int, C.c_int, _p, _i64, _p, C.c_float, _p]),
+    "ctn_rows_wgrad": (C.c_int, [_p, _i64, _p, _i64, _i64, C.c_int, C.c_int, _p, _i64, _p, C.c_float, C.c_int, _p]),
     "ctn_lstm_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "ctn_lstm_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "ctn_gemm_nn": (C.c_int, [C.POINTER(GemmNNArgs), _p]),

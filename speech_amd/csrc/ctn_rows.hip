@@ -155,15 +155,22 @@ __device__ __forceinline__ void rows_split3(const f32x4 v, ru32x2& hi, ru32x2& m
     }
 }
 
+// BM: output columns per block, 128 or 64 (narrow outputs -- the 64 features of the dual-path blocks -- waste half of the
+// matrix instructions and LDS of a 128-column tile).
+template <int BM>
 __global__ __launch_bounds__(RNTH) void rows_gemm_b3_kernel(const float* __restrict__ X, const int64_t ldx,
                                                             const float* __restrict__ W, const int64_t ldw,
                                                             const float* __restrict__ bias, const int64_t R, const int K,
                                                             const int M, float* __restrict__ Y, const int64_t ldy,
                                                             const bool xvec, const bool wvec, const bool yvec,
                                                             const unsigned tiles_m) {
-    constexpr int BR = 128, BM = 128, KC = 32, PB = 40;       // PB: bf16 per LDS row (32 + 8 of padding)
-    constexpr int PLANE = BR * PB;                            // bf16 per plane
-    __shared__ __attribute__((aligned(16))) __bf16 planes[6 * PLANE];
+    constexpr int BR = 128, KC = 32, PB = 40;                 // PB: bf16 per LDS row (32 + 8 of padding)
+    constexpr int PLANE = BR * PB, WPLANE = BM * PB;          // bf16 per plane of X and of W
+    constexpr int NJ = BM / 32;                               // accumulator tiles per wave
+    constexpr int OUTF = 4 * 32 * 68;                         // floats of the epilogue staging
+    constexpr int LDSB = (3 * PLANE + 3 * WPLANE) * 2 > OUTF * 4 ? (3 * PLANE + 3 * WPLANE) * 2 : OUTF * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDSB];
+    __bf16* const planes = reinterpret_cast<__bf16*>(lds_raw);
     __bf16* const Xp = planes;
     __bf16* const Wp = planes + 3 * PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,23 +179,25 @@ __global__ __launch_bounds__(RNTH) void rows_gemm_b3_kernel(const float* __restr
     const int64_t r0 = (int64_t)(blockIdx.x / tiles_m) * BR;
     const int m0 = (int)(blockIdx.x % tiles_m) * BM;
 
-    f32x16 acc[4];
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     const int lc = (tid & 7) * 4, lr = tid >> 3;     // thread -> (row lr + 32 q, 4 contraction indices at lc)
-    f32x4 rx[4], rw[4];
+    f32x4 rx[4], rw[NJ];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t r = r0 + lr + 32 * q;
             const int m = m0 + lr + 32 * q;
             rx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (r < R) rx[q] = rows_ld4(X + r * ldx + k0, lc, K - k0, xvec);
-            if (m < M) rw[q] = rows_ld4(W + (int64_t)m * ldw + k0, lc, K - k0, wvec);
+            if (q < NJ) {
+                rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M) rw[q] = rows_ld4(W + (int64_t)m * ldw + k0, lc, K - k0, wvec);
+            }
         }
     };
     auto stage = [&]() {
@@ -200,10 +209,12 @@ __global__ __launch_bounds__(RNTH) void rows_gemm_b3_kernel(const float* __restr
             *reinterpret_cast<ru32x2*>(&Xp[o]) = h;
             *reinterpret_cast<ru32x2*>(&Xp[PLANE + o]) = m;
             *reinterpret_cast<ru32x2*>(&Xp[2 * PLANE + o]) = l;
-            rows_split3(rw[q], h, m, l);
-            *reinterpret_cast<ru32x2*>(&Wp[o]) = h;
-            *reinterpret_cast<ru32x2*>(&Wp[PLANE + o]) = m;
-            *reinterpret_cast<ru32x2*>(&Wp[2 * PLANE + o]) = l;
+            if (q < NJ) {
+                rows_split3(rw[q], h, m, l);
+                *reinterpret_cast<ru32x2*>(&Wp[o]) = h;
+                *reinterpret_cast<ru32x2*>(&Wp[WPLANE + o]) = m;
+                *reinterpret_cast<ru32x2*>(&Wp[2 * WPLANE + o]) = l;
+            }
         }
     };
 
@@ -219,11 +230,11 @@ __global__ __launch_bounds__(RNTH) void rows_gemm_b3_kernel(const float* __restr
             const rbf16x8 am = *reinterpret_cast<const rbf16x8*>(&Xp[PLANE + ao]);
             const rbf16x8 al = *reinterpret_cast<const rbf16x8*>(&Xp[2 * PLANE + ao]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int bo = (j * 32 + l31) * PB + 16 * s + 8 * half;
                 const rbf16x8 bh = *reinterpret_cast<const rbf16x8*>(&Wp[bo]);
-                const rbf16x8 bm = *reinterpret_cast<const rbf16x8*>(&Wp[PLANE + bo]);
-                const rbf16x8 bl = *reinterpret_cast<const rbf16x8*>(&Wp[2 * PLANE + bo]);
+                const rbf16x8 bm = *reinterpret_cast<const rbf16x8*>(&Wp[WPLANE + bo]);
+                const rbf16x8 bl = *reinterpret_cast<const rbf16x8*>(&Wp[2 * WPLANE + bo]);
                 // smallest terms first
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
@@ -238,10 +249,9 @@ __global__ __launch_bounds__(RNTH) void rows_gemm_b3_kernel(const float* __restr
 
     // accumulators -> Y through LDS (the operand planes are free behind the loop's last barrier): each wave owns 8 KB,
     // a 32-row x 64-column half of its strip at a time, rows of 68 floats; then every lane stores 16 bytes, 16 lanes a row.
-    float* out = reinterpret_cast<float*>(planes) + wave * (32 * 68);
-    static_assert(4 * 32 * 68 * 4 <= 6 * PLANE * 2, "epilogue staging fits the operand planes");
+    float* out = reinterpret_cast<float*>(lds_raw) + wave * (32 * 68);
 #pragma unroll
-    for (int hc = 0; hc < 2; ++hc) {
+    for (int hc = 0; hc < BM / 64; ++hc) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = 2 * hc + jj;
@@ -273,6 +283,113 @@ __global__ __launch_bounds__(RNTH) void rows_gemm_b3_kernel(const float* __restr
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ short contractions (K <= 64)
+// Y = X W^T + b for K <= 64 (the LSTMs' input projection, 64 -> 1024, and the linear layers' input gradient), where the
+// output write is everything and the general kernel above spends its time on staging and barriers: here the weight
+// slab of a block's 128 output columns is split ONCE into LDS planes (all K at once) and the block then walks row tiles
+// without a barrier.  Each wave takes 32 rows at a time straight from global memory -- lane (row, half) loads the 32
+// contraction indices 32 half .. 32 half + 31 of its row, one full 128-byte line, and splits them in registers -- with
+// the roles of the operands swapped: the weights are the A operand (fragments from LDS), the rows the B operand, so the
+// accumulators hold four CONSECUTIVE output columns of one row per register group and leave as 16-byte stores
+// without a pass through LDS.  The next tile's rows are requested before the current tile's matrix instructions.
+// Contraction index of slot (k-step s, half h, element j): 32 h + 8 s + j, on both operands.
+__global__ __launch_bounds__(RNTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void rows_gemm_b3_k64_kernel(const float* __restrict__ X, const int64_t ldx, const float* __restrict__ W,
+                             const int64_t ldw, const float* __restrict__ bias, const int64_t R, const int K, const int M,
+                             float* __restrict__ Y, const int64_t ldy, const unsigned tiles_m, const bool wvec) {
+    constexpr int BM = 128, PB = 72;                      // 64 + 8 bf16 per LDS row: 16-byte reads of 16 rows cover all banks
+    constexpr int WPLANE = BM * PB;
+    __shared__ __attribute__((aligned(16))) __bf16 Wp[3 * WPLANE];
+    __shared__ __attribute__((aligned(16))) float bs[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = (int)(blockIdx.x % tiles_m) * BM;
+    const int64_t group = blockIdx.x / tiles_m, ngroups = gridDim.x / tiles_m;
+
+    // ---- the weight slab: 128 rows x 64 contraction indices, zero beyond M and K
+    {
+        const int lc = (tid & 15) * 4, lr = tid >> 4;     // thread -> (row lr + 16 q, 4 contraction indices at lc)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = m0 + lr + 16 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < M) v = rows_ld4(W + (int64_t)m * ldw, lc, K, wvec);
+            ru32x2 h, mi, l;
+            rows_split3(v, h, mi, l);
+            const int o = (lr + 16 * q) * PB + lc;
+            *reinterpret_cast<ru32x2*>(&Wp[o]) = h;
+            *reinterpret_cast<ru32x2*>(&Wp[WPLANE + o]) = mi;
+            *reinterpret_cast<ru32x2*>(&Wp[2 * WPLANE + o]) = l;
+        }
+        if (tid < BM) bs[tid] = (bias && m0 + tid < M) ? bias[m0 + tid] : 0.f;
+    }
+    __syncthreads();
+
+    const int64_t ntiles = (R + 31) / 32;
+    const int64_t stride = ngroups * 4;
+    int64_t tile = group * 4 + wave;
+    const int kbase = 32 * half;
+    f32x4 xv[8], xn[8];
+    auto fetch = [&](int64_t tl, f32x4 (&dst)[8]) {
+        int64_t r = tl * 32 + l31;
+        if (r > R - 1) r = R - 1;                          // clamped: rows beyond R are computed and not stored
+        const float* p = X + r * ldx + kbase;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = kbase + 4 * q;
+            dst[q] = ctn_ld4(p + (k < K ? 4 * q : 0));
+            if (!(k < K)) dst[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (tile < ntiles) fetch(tile, xv);
+    for (; tile < ntiles; tile += stride) {
+        if (tile + stride < ntiles) fetch(tile + stride, xn);
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            union { rbf16x8 v; ru32x2 p[2]; } bh, bm, bl;
+            rows_split3(xv[2 * s], bh.p[0], bm.p[0], bl.p[0]);
+            rows_split3(xv[2 * s + 1], bh.p[1], bm.p[1], bl.p[1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ao = (j * 32 + l31) * PB + kbase + 8 * s;
+                const rbf16x8 ah = *reinterpret_cast<const rbf16x8*>(&Wp[ao]);
+                const rbf16x8 am = *reinterpret_cast<const rbf16x8*>(&Wp[WPLANE + ao]);
+                const rbf16x8 al = *reinterpret_cast<const rbf16x8*>(&Wp[2 * WPLANE + ao]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh.v, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl.v, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm.v, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh.v, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm.v, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh.v, acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one k-step's fragments at a time: hoisted reads spill registers
+        }
+        // accumulator register 4 g + i of lane (l31, half) in tile j: output column m0 + 32 j + 8 g + 4 half + i of row l31
+        const int64_t r = tile * 32 + l31;
+        if (r < R) {
+            float* yrow = Y + r * ldy + m0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int mc = 32 * j + 8 * g + 4 * half;
+                    if (m0 + mc < M) {
+                        const f32x4 bv = ctn_ld4(&bs[mc]);
+                        ctn_st4(yrow + mc, f32x4{acc[j][4 * g] + bv[0], acc[j][4 * g + 1] + bv[1], acc[j][4 * g + 2] + bv[2],
+                                                 acc[j][4 * g + 3] + bv[3]});
+                    }
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = xn[q];
     }
 }
 
@@ -365,6 +482,151 @@ __global__ __launch_bounds__(RNTH) void rows_wgrad_kernel(const float* __restric
     if (do_bias && tid < TM && m0 + tid < M) atomicAdd(dbias + m0 + tid, sign * colsum);
 }
 
+// ------------------------------------------------------------------------------------------------ dW += dY^T X, six bf16 products
+// The weight gradient in the exact three-piece arithmetic.  The contraction runs over the ROWS of both operands, so the
+// matrix instruction wants, per lane, eight consecutive rows of one column: a transposed view of tiles that arrive
+// row-major.  The tiles are staged as they lie -- each thread splits the float4 it loaded and stores 8 bytes per piece
+// plane, [row][column] of bf16 -- and the fragments are fetched with ds_read_b64_tr_b16, the LDS's transposing read (per
+// group of 16 lanes a block of 4 rows x 16 columns comes back column-major: lane i receives column i of the four rows),
+// two reads per fragment and plane.  LDS image: rows of 256 bytes (128 bf16), the 16-byte chunk ch of row r stored at
+// chunk ch ^ (((r & 3) << 2) | ((r >> 2) & 3)), which keeps both the 8-byte stores and the transposing reads off each
+// other's banks.  Block: 128 x 64 output tile (wave w: rows 32 w .. 32 w + 31, both column tiles), stages of 32 rows.
+typedef short rs16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int rows_img_off(const int row, const int ch) {      // byte offset of a 16-byte chunk
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__global__ __launch_bounds__(RNTH) void rows_wgrad_b3_kernel(const float* __restrict__ dY, const int64_t lddy,
+                                                             const float* __restrict__ X, const int64_t ldx, const int64_t R,
+                                                             const int M, const int K, float* __restrict__ dW,
+                                                             const int64_t lddw, float* __restrict__ dbias, const float sign,
+                                                             const int64_t rchunk, const bool yvec, const bool xvec) {
+    constexpr int TM = 128, TK = 64, RS = 32;
+    constexpr int PLANEB = RS * 256;                      // bytes of one piece plane (32 rows x 256 bytes)
+    __shared__ __attribute__((aligned(16))) unsigned char Yp[3 * PLANEB];
+    __shared__ __attribute__((aligned(16))) unsigned char Xp[3 * PLANEB];
+    __shared__ float csum[4][TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TK;
+    const int64_t rb = (int64_t)blockIdx.z * rchunk, re = rb + rchunk < R ? rb + rchunk : R;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+
+    // loaders: dY tile 32 x 128 = 1024 float4 (four per thread: row tid / 32 + 8 q, columns 4 (tid % 32)); X tile 32 x 64 =
+    // 512 float4 (two per thread: row tid / 16 + 16 q, columns 4 (tid % 16))
+    const int yc = (tid & 31) * 4, yr = tid >> 5;
+    const int xc = (tid & 15) * 4, xr = tid >> 4;
+    f32x4 ry[4], rx[2];
+    auto fetch = [&](int64_t r_stage) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t r = r_stage + yr + 8 * q;
+            ry[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < re) ry[q] = rows_ld4(dY + r * lddy + m0, yc, M - m0, yvec);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t r = r_stage + xr + 16 * q;
+            rx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < re) rx[q] = rows_ld4(X + r * ldx + k0, xc, K - k0, xvec);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ru32x2 h, m, l;
+            rows_split3(ry[q], h, m, l);
+            const int o = rows_img_off(yr + 8 * q, yc >> 3) + (yc & 4) * 2;
+            *reinterpret_cast<ru32x2*>(Yp + o) = h;
+            *reinterpret_cast<ru32x2*>(Yp + PLANEB + o) = m;
+            *reinterpret_cast<ru32x2*>(Yp + 2 * PLANEB + o) = l;
+            if (do_bias) colsum += ry[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ru32x2 h, m, l;
+            rows_split3(rx[q], h, m, l);
+            const int o = rows_img_off(xr + 16 * q, xc >> 3) + (xc & 4) * 2;
+            *reinterpret_cast<ru32x2*>(Xp + o) = h;
+            *reinterpret_cast<ru32x2*>(Xp + PLANEB + o) = m;
+            *reinterpret_cast<ru32x2*>(Xp + 2 * PLANEB + o) = l;
+        }
+    };
+    // transposing read of one fragment: rows r0 .. r0 + 7 of 32 columns starting at c0 (a multiple of 32), this lane's
+    // column being c0 + l31.  Lane 4 q + p of a 16-lane group supplies row q, columns 4 p .. 4 p + 3 of its group's block.
+    const int gq = (lane & 15) >> 2, gp = lane & 3, gblk = ((lane >> 4) & 1) * 16, ghalf = lane >> 5;
+    auto frag = [&](const unsigned char* plane, const int s, const int c0) -> rbf16x8 {
+        const int r0 = 16 * s + 8 * ghalf;
+        const int col = c0 + gblk + 4 * gp;                 // first of this lane's four address columns
+        union { rbf16x8 v; rs16x4 h[2]; } u;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int row = r0 + 4 * x + gq;
+            const unsigned char* ptr = plane + rows_img_off(row, col >> 3) + (col & 4) * 2;
+            u.h[x] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs16x4*)(ptr));
+        }
+        return u.v;
+    };
+
+    if (rb < re) {
+        fetch(rb);
+        for (int64_t rs = rb; rs < re; rs += RS) {
+            stage();
+            __syncthreads();
+            if (rs + RS < re) fetch(rs + RS);
+#pragma unroll
+            for (int s = 0; s < RS / 16; ++s) {
+                const rbf16x8 ah = frag(Yp, s, wave * 32), am = frag(Yp + PLANEB, s, wave * 32),
+                              al = frag(Yp + 2 * PLANEB, s, wave * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const rbf16x8 bh = frag(Xp, s, j * 32), bm = frag(Xp + PLANEB, s, j * 32),
+                                  bl = frag(Xp + 2 * PLANEB, s, j * 32);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + j * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (m < M && k < K) atomicAdd(dW + (int64_t)m * lddw + k, sign * acc[j][e]);
+        }
+    }
+    if (do_bias) {          // a thread summed columns yc .. yc + 3 over its rows: fold the 8 row groups through LDS
+        // (csum is not an operand plane: no barrier is needed in front of these stores)
+        if (yr < 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[yr][yc + e] = 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&csum[yr & 3][yc + e], colsum[e]);
+        __syncthreads();
+        if (tid < TM && m0 + tid < M)
+            atomicAdd(dbias + m0 + tid, sign * ((csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid])));
+    }
+}
+
 }  // namespace
 
 extern "C" int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_is_km, const float* bias,
@@ -372,7 +634,10 @@ extern "C" int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_
     CTN_REQUIRE(X && W && Y, "ctn_rows_gemm: null pointer");
     CTN_REQUIRE(R > 0 && K > 0 && M > 0, "ctn_rows_gemm: empty shape");
     CTN_REQUIRE(ldx >= K && ldy >= M && ldw >= (w_is_km ? M : K), "ctn_rows_gemm: a row stride shorter than the row");
-    const unsigned tiles_m = (unsigned)ctn_cdiv(M, 128);
+    // the three-piece kernel has a 64-column form for narrow outputs
+    const bool b3 = !w_is_km && arith != CTN_ARITH_F32;
+    const int bm = (b3 && M <= 64) ? 64 : 128;
+    const unsigned tiles_m = (unsigned)ctn_cdiv(M, bm);
     CTN_REQUIRE((R + 127) / 128 * tiles_m <= 0x7fffffff, "ctn_rows_gemm: too many tiles");
     CTN_REQUIRE(arith == CTN_ARITH_DEFAULT || arith == CTN_ARITH_F32 || arith == CTN_ARITH_BF16X3,
                 "ctn_rows_gemm: arith is CTN_ARITH_DEFAULT, CTN_ARITH_F32 or CTN_ARITH_BF16X3");
@@ -380,31 +645,54 @@ extern "C" int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_
     const bool wvec = ctn_aligned16(W) && ldw % 4 == 0;
     const bool yvec = ctn_aligned16(Y) && ldy % 4 == 0;
     dim3 grid((unsigned)((R + 127) / 128 * tiles_m));
+    if (b3 && K <= 64 && K % 4 == 0 && M % 4 == 0 && xvec && yvec) {
+        // short contraction: resident blocks walk the row tiles (two blocks per CU, every column tile in flight at once)
+        const unsigned tm = (unsigned)ctn_cdiv(M, 128);
+        int64_t groups = 512 / tm;
+        if (groups < 1) groups = 1;
+        const int64_t max_groups = ((R + 31) / 32 + 3) / 4;       // a group's four waves take a row tile each
+        if (groups > max_groups) groups = max_groups;
+        hipLaunchKernelGGL(rows_gemm_b3_k64_kernel, dim3((unsigned)(groups * tm)), dim3(RNTH), 0, (hipStream_t)stream, X, ldx,
+                           W, ldw, bias, R, K, M, Y, ldy, tm, wvec);
+        CTN_CHECK_LAUNCH("ctn_rows_gemm");
+        return CTN_OK;
+    }
     if (w_is_km)        // the weight's rows are the contraction: f32 matrix instructions (both arithmetic modes)
         hipLaunchKernelGGL(rows_gemm_kernel<true>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
                            Y, ldy, xvec, wvec, tiles_m);
     else if (arith == CTN_ARITH_F32)
         hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
                            Y, ldy, xvec, wvec, tiles_m);
+    else if (bm == 64)
+        hipLaunchKernelGGL(rows_gemm_b3_kernel<64>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
+                           Y, ldy, xvec, wvec, yvec, tiles_m);
     else
-        hipLaunchKernelGGL(rows_gemm_b3_kernel, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M, Y,
-                           ldy, xvec, wvec, yvec, tiles_m);
+        hipLaunchKernelGGL(rows_gemm_b3_kernel<128>, grid, dim3(RNTH), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, R, K, M,
+                           Y, ldy, xvec, wvec, yvec, tiles_m);
     CTN_CHECK_LAUNCH("ctn_rows_gemm");
     return CTN_OK;
 }
 
 extern "C" int ctn_rows_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t R, int M, int K,
-                              float* dW, int64_t lddw, float* dbias, float sign, void* stream) {
+                              float* dW, int64_t lddw, float* dbias, float sign, int arith, void* stream) {
     CTN_REQUIRE(dY && X && dW, "ctn_rows_wgrad: null pointer");
     CTN_REQUIRE(R > 0 && K > 0 && M > 0, "ctn_rows_wgrad: empty shape");
     CTN_REQUIRE(lddy >= M && ldx >= K && lddw >= K, "ctn_rows_wgrad: a row stride shorter than the row");
+    CTN_REQUIRE(arith == CTN_ARITH_DEFAULT || arith == CTN_ARITH_F32 || arith == CTN_ARITH_BF16X3,
+                "ctn_rows_wgrad: arith is CTN_ARITH_DEFAULT, CTN_ARITH_F32 or CTN_ARITH_BF16X3");
     const bool yvec = ctn_aligned16(dY) && lddy % 4 == 0;
     const bool xvec = ctn_aligned16(X) && ldx % 4 == 0;
+    // The three-piece kernel runs on explicit request only (128-row output tiles: M > 64).  At the dual-path blocks'
+    // shapes it is the slower of the two -- 1024 x 64 over 511 104 rows: 850 against 780 us, 512 x 128: 772 against 686 --
+    // because with a 32-row stage between two barriers its 24 matrix instructions per wave (768 cycles) no longer cover
+    // the split, the LDS traffic and the barriers, which the f32 form's 32 instructions (2048 cycles) do.
+    const bool b3 = arith == CTN_ARITH_BF16X3 && M > 64;
     const int TM = M > 64 ? 128 : 64;
     const int tiles = ctn_cdiv(M, TM) * ctn_cdiv(K, 64);
     CTN_REQUIRE(ctn_cdiv(K, 64) <= 65535, "ctn_rows_wgrad: too many column tiles");
-    // one generation of resident blocks (about four per CU), chunks of whole 32-row stages, at least 256 rows each
-    int64_t nchunks = 1024 / tiles;
+    // one generation of resident blocks (about four per CU; three for the three-piece kernel's 48 KB of planes), chunks of
+    // whole 32-row stages, at least 256 rows each
+    int64_t nchunks = (b3 ? 768 : 1024) / tiles;
     if (nchunks < 1) nchunks = 1;
     int64_t rchunk = (R + nchunks - 1) / nchunks;
     rchunk = (rchunk + 31) / 32 * 32;
@@ -412,7 +700,10 @@ extern "C" int ctn_rows_wgrad(const float* dY, int64_t lddy, const float* X, int
     nchunks = (R + rchunk - 1) / rchunk;
     CTN_REQUIRE(nchunks <= 65535, "ctn_rows_wgrad: too many row chunks");
     dim3 grid(ctn_cdiv(M, TM), ctn_cdiv(K, 64), (unsigned)nchunks);
-    if (TM == 128)
+    if (b3)
+        hipLaunchKernelGGL(rows_wgrad_b3_kernel, grid, dim3(RNTH), 0, (hipStream_t)stream, dY, lddy, X, ldx, R, M, K, dW, lddw,
+                           dbias, sign, rchunk, yvec, xvec);
+    else if (TM == 128)
         hipLaunchKernelGGL(rows_wgrad_kernel<128>, grid, dim3(RNTH), 0, (hipStream_t)stream, dY, lddy, X, ldx, R, M, K, dW,
                            lddw, dbias, sign, rchunk, yvec, xvec);
     else

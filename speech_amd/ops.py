@@ -338,7 +338,7 @@ def rows_gemm(x, w, bias=None, w_is_km=False, arith=None):
     return y
 
 
-def rows_wgrad(dy, x, dW=None, dbias=None, sign=1.0):
+def rows_wgrad(dy, x, dW=None, dbias=None, sign=1.0, arith=None):
     """dW (M, K) += sign * dy^T x over the rows of dy (R, M) and x (R, K); dbias (M,) += sign * column sums of dy when
     given.  dW None: a zeroed (M, K) tensor is made and returned; see ctn_rows_wgrad."""
     lib = _lib.load()
@@ -353,8 +353,9 @@ def rows_wgrad(dy, x, dW=None, dbias=None, sign=1.0):
         assert dbias.dtype == torch.float32 and dbias.numel() == M and dbias.is_contiguous()
     if R == 0:
         return dW
+    arith = _lib.ARITH_DEFAULT if arith is None else arith        # default: f32 matrix instructions, the faster form here
     _lib.check(lib.ctn_rows_wgrad(_ptr(dy), _ld(dy), _ptr(x), _ld(x), R, M, K, _ptr(dW), _ld(dW), _ptr(dbias), float(sign),
-                                  _stream()), "ctn_rows_wgrad")
+                                  arith, _stream()), "ctn_rows_wgrad")
     return dW
 
 

@@ -35,18 +35,20 @@ def test_rows_gemm_matches_float64(R, K, M, w_is_km, arith):
 
 
 @pytest.mark.parametrize("R,K,M", SHAPES)
-def test_rows_wgrad_matches_float64(R, K, M):
-    from speech_amd import ops
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_rows_wgrad_matches_float64(R, K, M, arith):
+    from speech_amd import ops, _lib
+    arith = {"f32": _lib.ARITH_F32, "bf16x3": _lib.ARITH_BF16X3}[arith]
     dy = synth.normal((R, M), 4)
     x = synth.normal((R, K), 5)
     ref = dy.double().t() @ x.double()
     db = torch.zeros(M, device=DEV)
-    dW = ops.rows_wgrad(dy.to(DEV), x.to(DEV), dbias=db)
+    dW = ops.rows_wgrad(dy.to(DEV), x.to(DEV), dbias=db, arith=arith)
     torch.cuda.synchronize()
     assert_close(dW, ref, TOL, "dW")
     assert_close(db, dy.double().sum(0), TOL, "dbias")
     # the subtracting form takes the same product out again: what is left is rounding of the atomics' order
-    ops.rows_wgrad(dy.to(DEV), x.to(DEV), dW=dW, sign=-1.0)
+    ops.rows_wgrad(dy.to(DEV), x.to(DEV), dW=dW, sign=-1.0, arith=arith)
     torch.cuda.synchronize()
     assert float(dW.abs().max()) <= 1e-5 * float(ref.abs().max())
 

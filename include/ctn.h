@@ -228,6 +228,39 @@ int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_t ldw, int 
 int ctn_rows_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t R, int M, int K, float* dW,
                    int64_t lddw, float* dbias, float sign, int arith, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward pass of a residual layer's two pointwise heads in one launch: what ctn_gemm_nn (heads' input gradient with the
+ * CTN_EPI_NORMBWD sums) and ctn_gemm_nt (heads' weight and bias gradients) compute in two, with y2 and dY read once.
+ * Reference: the output / skip Conv1d(H, B, 1) pair of src/models/tdcn.py:172-175,190-194 behind the norm of :187 (gLN).
+ *   dY   = [dY1 (M1 rows: gradient at the residual output; M1 = 0 for a layer without it); dY2 (M2 rows: at the skip output)]
+ *   dn2[b][c][t]  = sum_m Wh[m][c] dY[b][m][t]                     (written; (batch, H, T), row pitch lddn2)
+ *   esums[b][slot][0] += sum_{c,t} gamma[c] dn2,   [1] += sum_{c,t} gamma[c] dn2 xhat2,  xhat2 = (prelu(y2) - mean_b) rstd_b
+ *   dW1[m][c] += sum_{b,t} dY1[b][m][t] n2[b][c][t],  dW2 likewise,  n2 = gamma xhat2 + beta       (float atomics)
+ *   rowsum1[m] += sum_{b,t} dY1[b][m][t],  rowsum2 likewise          (the bias gradients; either may be null)
+ * W_prep: the (M1 + M2) x H matrix A[k = m][c] = Wh[m][c] in prepared form (ctn_weight_prep).  H % 128 == 0,
+ * M1 + M2 = 128 or 256 with both multiples of 32, T >= 4, gLN statistics (one mean / rstd per batch element, stride ssb);
+ * arithmetic CTN_ARITH_BF16X3.  Accumulated outputs are zeroed by the caller.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, T, H;
+    int32_t M1, M2;
+    const float* dY1; int64_t lddy1, dy1bs;
+    const float* dY2; int64_t lddy2, dy2bs;
+    const float* y2;  int64_t ldy2, y2bs;
+    const float* alpha;
+    const float* mean; const float* rstd; int64_t ssb;
+    const float* gamma; const float* beta;
+    const void* W_prep;
+    float* dn2; int64_t lddn2, dn2bs;
+    double* esums;
+    float* dW1; int64_t lddw1;
+    float* dW2; int64_t lddw2;
+    float* rowsum1; float* rowsum2;
+    int32_t ldmin, pad0;              /* set by the library */
+} ctn_heads_bwd_args;
+int ctn_sizeof_heads_bwd_args(void);
+int ctn_heads_bwd(const ctn_heads_bwd_args* args, void* stream);
+
 /* Finishing a global layer norm's reduction inside the launch that produces its sums (field `fin` of the argument structs
  * below; it applies to that launch's `esums` / `isums`).  With `count` given, the block that adds the LAST partial sums
  * of a batch element also turns the element's sums into the two scalars the consumers read, so no launch of

@@ -135,6 +135,25 @@ class DwBwdArgs(C.Structure):
     ]
 
 
+class HeadsBwdArgs(C.Structure):
+    _fields_ = [
+        ("batch", _i32), ("T", _i32), ("H", _i32), ("M1", _i32), ("M2", _i32),
+        ("dY1", _p), ("lddy1", _i64), ("dy1bs", _i64),
+        ("dY2", _p), ("lddy2", _i64), ("dy2bs", _i64),
+        ("y2", _p), ("ldy2", _i64), ("y2bs", _i64),
+        ("alpha", _p),
+        ("mean", _p), ("rstd", _p), ("ssb", _i64),
+        ("gamma", _p), ("beta", _p),
+        ("W_prep", _p),
+        ("dn2", _p), ("lddn2", _i64), ("dn2bs", _i64),
+        ("esums", _p),
+        ("dW1", _p), ("lddw1", _i64),
+        ("dW2", _p), ("lddw2", _i64),
+        ("rowsum1", _p), ("rowsum2", _p),
+        ("ldmin", _i32), ("pad0", _i32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/ctn.h declares
 PROTOTYPES = {
     "ctn_version": (C.c_char_p, []),
@@ -143,6 +162,8 @@ PROTOTYPES = {
     "ctn_sizeof_gemm_nt_args": (C.c_int, []),
     "ctn_sizeof_dw_fwd_args": (C.c_int, []),
     "ctn_sizeof_dw_bwd_args": (C.c_int, []),
+    "ctn_sizeof_heads_bwd_args": (C.c_int, []),
+    "ctn_heads_bwd": (C.c_int, [C.POINTER(HeadsBwdArgs), _p]),
     "ctn_probe_copy": (C.c_int, [_p, _p, _p, _i64, _p]),
     "ctn_probe_stream": (C.c_int, [_p, _p, _i64, C.c_int, _p]),
     "ctn_probe_mfma_f32": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
@@ -206,6 +227,7 @@ _STRUCT_SIZES = {
     "ctn_sizeof_gemm_nt_args": GemmNTArgs,
     "ctn_sizeof_dw_fwd_args": DwFwdArgs,
     "ctn_sizeof_dw_bwd_args": DwBwdArgs,
+    "ctn_sizeof_heads_bwd_args": HeadsBwdArgs,
     "ctn_sizeof_wprep_item": WPrepItem,
     "ctn_sizeof_transpose_item": TransposeItem,
 }

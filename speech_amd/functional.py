@@ -46,6 +46,13 @@ USE_PREPARED_WEIGHTS = os.environ.get("CTN_PREPARED_WEIGHTS", "1") != "0"
 # applied to; with f32 MFMAs both routes are at 1e-4).  tools/diag_heads_coefs.py measures it.
 HEADS_COEFS_FROM_WGRAD = os.environ.get("CTN_HEADS_COEFS_FROM_WGRAD", "0") != "0"
 
+# The backward pass of a layer's two heads as ONE launch (ctn_heads_bwd: the input gradient with its norm sums and the
+# weight / bias gradients share one pass over dY and y2) instead of a ctn_gemm_nn and a ctn_gemm_nt launch.  gLN, the
+# three-piece arithmetic and prepared weights only.  Opt-in (CTN_FUSED_HEADS_BWD=1): it moves a third less data, but
+# with one 142 KB block per CU its phases do not overlap and the launch takes 598 us against 463 us for the pair inside
+# a step at the benchmark's batch (35.3 against 34.7 ms per step; analysis in csrc/ctn_heads_bwd.hip).
+FUSED_HEADS_BWD = os.environ.get("CTN_FUSED_HEADS_BWD", "0") != "0"
+
 _ZERO_ROWS = {}
 
 
@@ -365,6 +372,17 @@ def layer_backward(L, saved, dout, dskip, sink, dilation, causal, eps):
             Hdp = None if L.dual else _prepared(L.planes, "Hd", *parts["Hd"][:2], parts["Hd"][3], dev)
             ops.gemm_nn(H, T, Sc, B, Ws2, H, dskip, dn2, emode=EPI_STORE, A_prep=Hdp)
         return _layer_backward_tail(L, saved, dn2, dout, dual, sink, dilation, causal, eps, parts)
+    if FUSED_HEADS_BWD and not causal and dual == L.dual and ops.heads_bwd_usable(M1, Sc, H, T, st2, y2) \
+            and "gemm" not in ops.FOLD_FINISH:
+        # one launch for the heads' whole backward pass: input gradient with its norm sums, weight and bias gradients
+        Hdp = _prepared(L.planes, "Hd", *parts["Hd"][:2], parts["Hd"][3], dev, K1=Bc if dual else None)
+        if Hdp is not None:
+            bacc2 = Accum(B, T, causal, dev)
+            ops.heads_bwd(dout if dual else None, dskip, y2, L.a2, st2, L.g2.view(-1), L.be2.view(-1), Hdp, dn2, bacc2,
+                          sink.g(o["Wo"]).view(Bc, H) if dual else None, sink.g(o["Ws"]).view(Sc, H),
+                          sink.g(o["bo"]) if dual else None, sink.g(o["bs"]))
+            ops.bwd_coefs(bacc2, st2, B, H, T, eps)
+            return _layer_backward_tail(L, saved, dn2, dout, dual, sink, dilation, causal, eps, parts)
     # heads: input gradient with the norm-2 backward sums in the epilogue
     bacc2 = Accum(B, T, causal, dev)
     finb2 = ops.coefs_request(bacc2, st2, B, H, T)

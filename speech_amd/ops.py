@@ -693,6 +693,40 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
     _lib.check(lib.ctn_gemm_nt(C.byref(a), _stream()), "ctn_gemm_nt")
 
 
+def heads_bwd_usable(M1, M2, H, T, stat, y2=None):
+    """True when ctn_heads_bwd takes these head shapes in the current arithmetic (three bf16 pieces, gLN); y2, when
+    given, is checked against the kernel's 32-bit byte offsets (the widest tensor it reads)."""
+    if y2 is not None and ((y2.shape[0] - 1) * y2.stride(0) + H * y2.stride(1)) * 4 >= 0x7ffffff0:
+        return False
+    return (_gemm_split == 3 and H % 128 == 0 and M1 % 32 == 0 and M2 % 32 == 0 and M2 > 0 and (M1 + M2) in (128, 256)
+            and T >= 4 and stat is not None and not stat.cln)
+
+
+def heads_bwd(dY1, dY2, y2, alpha, stat, gamma, beta, W_prep, dn2, eacc, dW1, dW2, rowsum1, rowsum2):
+    """The backward pass of a layer's two pointwise heads in one launch (ctn_heads_bwd in include/ctn.h): dn2 and its
+    norm sums (into eacc), the weight gradients dW1 (M1, H) / dW2 (M2, H) and the bias gradients, from dY1 (B, M1, T) or
+    None, dY2 (B, M2, T), the pre-activation y2 (B, H, T) and the prepared (M1 + M2) x H input-gradient matrix."""
+    lib = _lib.load()
+    a = _lib.HeadsBwdArgs()
+    B, H, T = y2.shape
+    a.batch, a.T, a.H = B, T, H
+    a.M1, a.M2 = (0 if dY1 is None else dY1.shape[1]), dY2.shape[1]
+    if dY1 is not None:
+        a.dY1, a.lddy1, a.dy1bs = _ptr(dY1), dY1.stride(1), dY1.stride(0)
+        a.dW1, a.lddw1 = _ptr(dW1), dW1.stride(0)
+    a.dY2, a.lddy2, a.dy2bs = _ptr(dY2), dY2.stride(1), dY2.stride(0)
+    a.dW2, a.lddw2 = _ptr(dW2), dW2.stride(0)
+    a.y2, a.ldy2, a.y2bs = _ptr(y2), y2.stride(1), y2.stride(0)
+    a.alpha = _ptr(alpha)
+    a.mean, a.rstd, a.ssb = _ptr(stat.mean), _ptr(stat.rstd), stat.sb
+    a.gamma, a.beta = _ptr(gamma), _ptr(beta)
+    a.W_prep = _ptr(W_prep)
+    a.dn2, a.lddn2, a.dn2bs = _ptr(dn2), dn2.stride(1), dn2.stride(0)
+    a.esums = _ptr(eacc.sums)
+    a.rowsum1, a.rowsum2 = _ptr(rowsum1), _ptr(rowsum2)
+    _lib.check(lib.ctn_heads_bwd(C.byref(a), _stream()), "ctn_heads_bwd")
+
+
 # ------------------------------------------------------------------------------------------------ depthwise
 def dw_fwd(x, w, bias, y, dilation, pad_left, *, xflags=0, alpha_in=None, stat=None, gamma=None, beta=None,
            alpha_out=None, acc=None, stats=True, fin=None):

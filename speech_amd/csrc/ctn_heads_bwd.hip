@@ -31,7 +31,12 @@
 // the first barrier (1 k) and the epilogue (5-7 k: accumulator drain, four barriers, the join with n2) run with the
 // matrix pipe idle.  Counters: matrix pipe busy 33 % of the launch (44 % over the pair), LDS active 28 %, LDS bank
 // conflicts 0.4 %.  Neither a second accumulation chain nor reading the fragments a sub-step ahead changed the time:
-// the loss is in the exposed phases, which a second resident block would cover (this one needs 142 KB of LDS).
+// the loss is in the exposed phases.  A second resident block does not cover them either: with slices of 64 channels,
+// blocks of four waves and 75 KB of LDS (two blocks per CU, the staging rows aliased onto the idle weight buffer) the
+// same stamps show owner-wave steps of 2.5-2.9 k cycles again and the launch takes 659 us.  The wave that owns a
+// k-tile's weight gradient issues 36 matrix instructions per step from 32 x 32 tiles that need one 6 KB set of LDS
+// fragments per 6 instructions; with both accumulator sets resident (16 + 64 registers) no operand can stay in
+// registers across tiles as in ctn_gemm_nn / ctn_gemm_nt, and the fragment reads' latency paces the step.
 //
 // LDS image of the [row][64 frames] bf16 planes: rows of 128 bytes, 16-byte chunk ch of row r at chunk
 // ch ^ (((r >> 2) & 3) | (((r >> 1) & 1) << 2)).  With it the 16-byte row reads (16 lanes = 16 rows of one chunk), the

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from ..functional import ConvTasNetFn, SeparatorFn, Layer, LayerNormFn, Conv1x1Fn
 from ..utils.filterbank import choose_filterbank
 from ..utils.model import choose_nonlinear
-from ..utils.tasnet import choose_layer_norm
+from ..utils.tasnet import choose_layer_norm, frame_padding, waveform_rows, decode_sources
 from .tdcn import TimeDilatedConvNet, _norm_params
 
 EPS = 1e-12
@@ -120,44 +120,15 @@ class ConvTasNet(nn.Module):
             output (batch_size, n_sources, T) or (batch_size, n_sources, C_in, T)
             latent (batch_size, n_sources, n_basis, T'), where T' = (T-K)//S+1
         """
-        n_sources, n_basis = self.n_sources, self.n_basis
-        kernel_size, stride = self.kernel_size, self.stride
-        n_dims = input.dim()
-
-        if n_dims == 3:
-            batch_size, C_in, T = input.size()
-            assert C_in == 1, "input.size() is expected (?, 1, ?), but given {}".format(input.size())
-        elif n_dims == 4:
-            batch_size, C_in, n_mics, T = input.size()
-            assert C_in == 1, "input.size() is expected (?, 1, ?, ?), but given {}".format(input.size())
-            input = input.view(batch_size, n_mics, T)
-        else:
-            raise ValueError("Not support {} dimension input".format(n_dims))
-
-        padding = (stride - (T - kernel_size) % stride) % stride
-        padding_left = padding // 2
-        padding_right = padding - padding_left
-
-        input = F.pad(input, (padding_left, padding_right))
-        w = self.encoder(input)
+        rows, mics = waveform_rows(input)
+        left, right = frame_padding(rows.size(-1), self.kernel_size, self.stride)
+        w = self.encoder(F.pad(rows, (left, right)))
         if torch.is_complex(w):     # complex Fourier latent: the mask scales the magnitude, the phase is kept (:152-156)
-            amplitude, phase = torch.abs(w), torch.angle(w)
-            mask = self.separator(amplitude)
-            w_hat = amplitude.unsqueeze(dim=1) * mask * torch.exp(1j * phase.unsqueeze(dim=1))
+            magnitude = torch.abs(w)
+            latent = (magnitude.unsqueeze(1) * self.separator(magnitude)) * torch.exp(1j * torch.angle(w)).unsqueeze(1)
         else:
-            mask = self.separator(w)
-            w = w.unsqueeze(dim=1)
-            w_hat = w * mask
-
-        latent = w_hat
-        w_hat = w_hat.reshape(batch_size * n_sources, n_basis, -1)
-        x_hat = self.decoder(w_hat)
-        if n_dims == 3:
-            x_hat = x_hat.view(batch_size, n_sources, -1)
-        else:
-            x_hat = x_hat.view(batch_size, n_sources, n_mics, -1)
-        output = F.pad(x_hat, (-padding_left, -padding_right))
-        return output, latent
+            latent = self.separator(w) * w.unsqueeze(1)
+        return decode_sources(self.decoder, latent, mics, left, right), latent
 
     def get_config(self):
         config = {

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from ..functional import Conv1x1Fn, SegmentFn, OverlapAddFn
 from ..utils.filterbank import choose_filterbank
-from ..utils.tasnet import choose_layer_norm
+from ..utils.tasnet import choose_layer_norm, frame_padding, waveform_rows, decode_sources
 from .dprnn import DPRNN
 from .transform import Segment1d, OverlapAdd1d
 
@@ -73,38 +73,11 @@ class DPRNNTasNet(nn.Module):
             output (batch_size, n_sources, T)
             latent (batch_size, n_sources, n_basis, T'), where T' = (T-K)//S+1
         """
-        n_sources, n_basis = self.n_sources, self.n_basis
-        kernel_size, stride = self.kernel_size, self.stride
-        n_dim = input.dim()
-        if n_dim == 3:
-            batch_size, C_in, T = input.size()
-            assert C_in == 1, "input.size() is expected (?, 1, ?), but given {}".format(input.size())
-        elif n_dim == 4:
-            batch_size, C_in, n_mics, T = input.size()
-            assert C_in == 1, "input.size() is expected (?, 1, ?, ?), but given {}".format(input.size())
-            input = input.view(batch_size, n_mics, T)
-        else:
-            raise ValueError("Not support {} dimension input".format(n_dim))
-
-        padding = (stride - (T - kernel_size) % stride) % stride
-        padding_left = padding // 2
-        padding_right = padding - padding_left
-
-        input = F.pad(input, (padding_left, padding_right))
-        w = self.encoder(input)
-        mask = self.separator(w)
-        w = w.unsqueeze(dim=1)
-        w_hat = w * mask
-
-        latent = w_hat
-        w_hat = w_hat.reshape(batch_size * n_sources, n_basis, -1)
-        x_hat = self.decoder(w_hat)
-        if n_dim == 3:
-            x_hat = x_hat.view(batch_size, n_sources, -1)
-        else:
-            x_hat = x_hat.view(batch_size, n_sources, n_mics, -1)
-        output = F.pad(x_hat, (-padding_left, -padding_right))
-        return output, latent
+        rows, mics = waveform_rows(input)
+        left, right = frame_padding(rows.size(-1), self.kernel_size, self.stride)
+        w = self.encoder(F.pad(rows, (left, right)))
+        latent = self.separator(w) * w.unsqueeze(1)
+        return decode_sources(self.decoder, latent, mics, left, right), latent
 
     def get_config(self):
         config = {

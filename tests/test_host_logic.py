@@ -269,3 +269,29 @@ print('compat ok')
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "compat"))
     r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "compat ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_framing_helpers_follow_the_reference_arithmetic():
+    """frame_padding / waveform_rows / decode_sources (src/models/conv_tasnet.py:127-159): the shortfall to a whole number
+    of hops, its smaller half in front; (B, 1, mics, T) as rows per microphone; the framing zeros cut off after decoding."""
+    import torch
+    from speech_amd.utils.tasnet import frame_padding, waveform_rows, decode_sources
+    for T in (100, 101, 117, 32000, 31999):
+        for K, S in ((16, 8), (2, 1), (20, 10), (32, 16), (16, 4)):
+            left, right = frame_padding(T, K, S)
+            pad = (S - (T - K) % S) % S
+            assert (left, right) == (pad // 2, pad - pad // 2)
+            assert (T + left + right - K) % S == 0
+    rows, mics = waveform_rows(torch.zeros(3, 1, 50))
+    assert rows.shape == (3, 1, 50) and mics is None
+    rows, mics = waveform_rows(torch.arange(3 * 4 * 50.).view(3, 1, 4, 50))
+    assert rows.shape == (3, 4, 50) and mics == 4 and float(rows[2, 3, 49]) == 3 * 4 * 50 - 1
+    with pytest.raises(ValueError):
+        waveform_rows(torch.zeros(3, 50))
+    with pytest.raises(AssertionError):
+        waveform_rows(torch.zeros(3, 2, 50))
+    latent = torch.arange(2 * 3 * 5 * 7.).view(2, 3, 5, 7)
+    dec = lambda w: w.sum(dim=1, keepdim=True).repeat_interleave(2, dim=2)      # (B*S, 1, 14)
+    out = decode_sources(dec, latent, None, 2, 1)
+    assert out.shape == (2, 3, 11)
+    assert torch.equal(out[1, 2], latent[1, 2].sum(0).repeat_interleave(2)[2:13])

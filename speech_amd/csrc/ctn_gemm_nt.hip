@@ -421,15 +421,26 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT
             bb[j] -= bmean * bg[j];
         }
     }
-    f32x4 bmv[FK / 8], brv[FK / 8];                       // cLN: B statistics of this half-wave's frame groups
+    // cLN: B statistics of this half-wave's frame groups (frame-divided pairs: of the wave's own two groups).  They are
+    // requested one k-tile ahead, behind the barrier, so that they arrive under the matrix phase: fetched where they
+    // are used, every k-tile waits out a round trip to L2 in front of its barrier.
+    constexpr int NBS = KS ? 2 : FK / 8;
+    f32x4 bmv[NBS], brv[NBS], bmn[NBS], brn[NBS];
     auto load_bstat = [&](int t0) {
         if (BSTAT) {
 #pragma unroll
-            for (int c = 0; c < FK / 8; ++c) {
+            for (int i = 0; i < NBS; ++i) {
+                const int c = KS ? 2 * (wave & 1) + i : i;
                 const int tf = min(t0 + 4 * (2 * c + half), tstat);
-                bmv[c] = ctn_ld4(pbm + tf);
-                brv[c] = ctn_ld4(pbr + tf);
+                bmn[i] = ctn_ld4(pbm + tf);
+                brn[i] = ctn_ld4(pbr + tf);
             }
+        }
+    };
+    auto take_bstat = [&]() {
+        if (BSTAT) {
+#pragma unroll
+            for (int i = 0; i < NBS; ++i) bmv[i] = bmn[i], brv[i] = brn[i];
         }
     };
     // the two waves of a tile row read the same A rows: one of them reduces, and only in the first tile column
@@ -482,7 +493,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT
                             float w = v[e];
                             if (BXF & CTN_XF_PRELU) w = ctn_prelu_med(w, b_alpha, bplim);
                             if (BXF & CTN_XF_NORM)
-                                w = BSTAT ? (w - bmv[c][e]) * brv[c][e] * bg[j] + bb[j] : __builtin_fmaf(w, bg[j], bb[j]);
+                                w = BSTAT ? (w - bmv[KS ? u : c][e]) * brv[KS ? u : c][e] * bg[j] + bb[j]
+                                          : __builtin_fmaf(w, bg[j], bb[j]);
                             if (TAIL && !(tf + e < t_end)) w = 0.f;
                             b8[j][4 * u + e] = w;
                         }
@@ -605,14 +617,21 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT
     }
     const bool xreduce = BWD && tile_n == 0;
     const float ac1m = ac1 - amean * ac2;               // gLN: c1 + (u - mean) * c2 = fma(u, c2, ac1m)
+    // cLN: the four per-frame statistics of this thread's frame group, requested one k-tile before the transform that
+    // uses them (same reason as the B statistics above)
+    f32x4 am4, ar4, a14, a24, amn, arn, a1n, a2n;
+    auto load_astat = [&](int t0) {
+        if (BWD && CLN) {
+            const int ts = min(t0 + 4 * xgrp, tstat);
+            amn = ctn_ld4(pam + ts); arn = ctn_ld4(par + ts); a1n = ctn_ld4(pa1 + ts); a2n = ctn_ld4(pa2 + ts);
+        }
+    };
+    auto take_astat = [&]() {
+        if (BWD && CLN) am4 = amn, ar4 = arn, a14 = a1n, a24 = a2n;
+    };
     auto transform = [&](float* As, int t0) {
         float* A2s = As + FTA + FTB;
         const int tf = t0 + 4 * xgrp;
-        f32x4 am4, ar4, a14, a24;
-        if (CLN) {
-            const int ts = min(tf, tstat);
-            am4 = ctn_ld4(pam + ts); ar4 = ctn_ld4(par + ts); a14 = ctn_ld4(pa1 + ts); a24 = ctn_ld4(pa2 + ts);
-        }
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int o = (xrow + XRP * u) * FK + xslot * 4;
@@ -639,19 +658,21 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT
     const int nfull = (t_end - t_begin) / FK;             // k-tiles that lie wholly inside the chunk
     if (!BWD) {
         if (nk > 0) issue(t_begin, 0);
+        load_bstat(t_begin);
         for (int kt = 0; kt < nfull; ++kt) {
             const int t0 = t_begin + kt * FK;
-            load_bstat(t0);
             // every wave's pieces of tile kt must have landed before any wave reads the tile
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            take_bstat();
             __syncthreads();
             if (kt + 1 < nk) issue(t0 + FK, (kt + 1) & 1);
+            load_bstat(t0 + FK);
             compute(lds + (kt & 1) * BUF, t0, std::false_type{});
         }
         if (nfull < nk) {
             const int t0 = t_begin + nfull * FK;
-            load_bstat(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            take_bstat();
             __syncthreads();
             compute(lds + (nfull & 1) * BUF, t0, std::true_type{});
         }
@@ -665,21 +686,28 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(KS ? CTN_NT
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (nk > 1) issue(t_begin + FK, 1);
+            load_astat(t_begin);
+            take_astat();
             transform(lds, t_begin);
+            load_astat(t_begin + FK);
         }
+        load_bstat(t_begin);
         for (int kt = 0; kt < nfull; ++kt) {
             const int t0 = t_begin + kt * FK;
-            load_bstat(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 have landed
+            take_bstat();
+            take_astat();                                        // statistics of tile kt+1's frames
             __syncthreads();                                     // tile kt transformed, tile kt+1 complete, tile kt-1 free
+            load_bstat(t0 + FK);
+            load_astat(t0 + 2 * FK);
             if (kt + 2 < nk) issue(t0 + 2 * FK, (kt + 2) % 3);
             if (kt + 1 < nk) transform(lds + ((kt + 1) % 3) * BUF, t0 + FK);
             compute(lds + (kt % 3) * BUF, t0, std::false_type{});
         }
         if (nfull < nk) {
             const int t0 = t_begin + nfull * FK;
-            load_bstat(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            take_bstat();
             __syncthreads();                                     // the ragged tile has been transformed
             compute(lds + (nfull % 3) * BUF, t0, std::true_type{});
         }

@@ -339,15 +339,19 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
         mu4[j] = norm ? ctn_ld4(mrow + tt) : f32x4{0.f, 0.f, 0.f, 0.f};
         rs4[j] = norm ? ctn_ld4(rrow + tt) : f32x4{1.f, 1.f, 1.f, 1.f};
     }
-    for (int cg = c0; cg < cend; cg += CS) {
-        // ---- stage CS transformed, zero-padded rows; every load is issued before any is used
-        f32x4 v[NITC];
+    // the rows of a phase are requested as soon as the phase before has staged its own: they arrive under its taps
+    f32x4 v[NITC];
+    auto load_phase = [&](const int cg) {
 #pragma unroll
         for (int j = 0; j < NITC; ++j) {
             const int c = min(cg + rr[j], cend - 1);
             const int tt = min(max(tA + 4 * ii[j], 0), tl4);
             v[j] = CTN_DW_LD(a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx + tt);
         }
+    };
+    if (c0 < cend) load_phase(c0);
+    for (int cg = c0; cg < cend; cg += CS) {
+        // ---- stage CS transformed, zero-padded rows
 #pragma unroll
         for (int j = 0; j < NITC; ++j) {
             const int idx = tid + j * NTH;
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
             }
             ctn_st4(&lds[r * lw + 4 * i4], o);
         }
+        if (cg + CS < cend) load_phase(cg + CS);
         __syncthreads();
         // ---- taps: one float4 of output per thread and channel
         if (t < t_end) {
@@ -599,19 +604,30 @@ __global__ __launch_bounds__(NTH) void dw_bwd_kernel(const ctn_dw_bwd_args a, co
 // Sums NP (a power of two <= 32) per-lane values over a wave with NP - 1 + log2(64 / NP) exchanges instead of 6 * NP: at
 // every step a lane keeps one half of its values and hands the other half to its partner, so the values are spread
 // over the lanes while they are summed.  Returns, in every lane l, the wave total of value l % NP.
+// (The steps are template instances, not a loop over `step >>= 1`: the compiler does not unroll that loop, and the
+// array is then indexed at run time -- a sixteen-way chain of compares and selects in front of every exchange.)
+template <int NP, int STEP>
+struct wave_scatter_step {
+    static __device__ __forceinline__ void run(float (&v)[NP], const int lane) {
+        const bool upper = (lane & STEP) != 0;
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+            const float send = upper ? v[i] : v[i + STEP];
+            const float keep = upper ? v[i + STEP] : v[i];
+            v[i] = keep + __shfl_xor(send, STEP);
+        }
+        wave_scatter_step<NP, STEP / 2>::run(v, lane);
+    }
+};
+template <int NP>
+struct wave_scatter_step<NP, 0> {
+    static __device__ __forceinline__ void run(float (&)[NP], const int) {}
+};
 template <int NP>
 __device__ __forceinline__ float wave_sum_scatter(float (&v)[NP]) {
+    static_assert(NP >= 2 && NP <= 32 && (NP & (NP - 1)) == 0, "a power of two");
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int step = NP / 2; step >= 1; step >>= 1) {
-        const bool upper = (lane & step) != 0;
-#pragma unroll
-        for (int i = 0; i < step; ++i) {
-            const float send = upper ? v[i] : v[i + step];
-            const float keep = upper ? v[i + step] : v[i];
-            v[i] = keep + __shfl_xor(send, step);
-        }
-    }
+    wave_scatter_step<NP, NP / 2>::run(v, lane);
     float t = v[0];
 #pragma unroll
     for (int m = NP; m < 64; m <<= 1) t += __shfl_xor(t, m);
@@ -648,12 +664,10 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
     // per-frame statistics of this thread's staging columns
     f32x4 mu2[NITB], rs2[NITB], k1[NITB], k2[NITB], mu1[NITB], rs1[NITB];
     int ts[NITB];
-    bool in_row[NITB];
 #pragma unroll
     for (int j = 0; j < NITB; ++j) {
         const int i4 = tid + j * NTH;
         const int t = tA + 4 * i4;
-        in_row[j] = i4 < lw4 && t >= 0 && t < T;
         ts[j] = min(max(t, 0), tl4);
         const int64_t s2 = (int64_t)b * a.ssb2 + ts[j], s1 = (int64_t)b * a.ssb1 + ts[j];
         mu2[j] = ctn_ld4(a.mean2 + s2); rs2[j] = ctn_ld4(a.rstd2 + s2);
@@ -665,8 +679,11 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
     const int t = t0 + 4 * tid;                        // this thread's output frames (one float4 per channel)
     if (tid < MAXPH * NP) chan[tid] = 0.f;             // visible after the first barrier of the loop
 
-    for (int cg = c0; cg < cend; cg += CS) {
-        f32x4 vdn[CS][NITB], vx[CS][NITB], vy[CS][NITB];
+    // The rows of a phase are requested as soon as the previous phase has staged its own (the registers are free from
+    // then on), so they arrive under that phase's tap loops and reductions: at two blocks per CU a phase that fetches
+    // its rows where it needs them waits out the whole memory latency eight times per block.
+    f32x4 vdn[CS][NITB], vx[CS][NITB], vy[CS][NITB];
+    auto load_phase = [&](const int cg) {
 #pragma unroll
         for (int r = 0; r < CS; ++r) {
             const int c = min(cg + r, cend - 1);
@@ -677,6 +694,9 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
                 vx[r][j] = CTN_DW_LD(a.x + (int64_t)b * a.xbs + (int64_t)c * a.ldx + ts[j]);
             }
         }
+    };
+    if (c0 < cend) load_phase(c0);
+    for (int cg = c0; cg < cend; cg += CS) {
         float v[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) v[i] = 0.f;
@@ -691,11 +711,16 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
             for (int j = 0; j < NITB; ++j) {
                 const int i4 = tid + j * NTH;
                 if (i4 >= lw4) continue;
-                const int tj = tA + 4 * i4;
+                // The frame index passes through an opaque move once per phase: the validity masks below depend on
+                // nothing else, the compiler would otherwise keep all sixteen of them (64-bit lane masks) alive across
+                // the phases, and with the scalar registers gone they come back through v_readlane -- a quarter of the
+                // loop's vector instructions.  Recomputing them is four compares each.
+                int tj = tA + 4 * i4;
+                asm volatile("" : "+v"(tj));
                 f32x4 dv, xv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool valid = ch_ok && in_row[j] && tj + e < T;
+                    const bool valid = ch_ok && tj + e >= 0 && tj + e < T;
                     const bool interior = valid && tj + e >= t0 && tj + e < t_end;
                     const float dn = vdn[r][j][e], y2 = vy[r][j][e];
                     const float sl = y2 > 0.f ? 1.f : a2;
@@ -715,6 +740,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
             }
             v[r * NV + 0] = dgamma2; v[r * NV + 1] = dbeta2; v[r * NV + 2] = dbias;
         }
+        if (cg + CS < cend) load_phase(cg + CS);
         __syncthreads();
         // ---- input gradient, weight gradient, norm-1 reductions
         if (t < t_end) {

@@ -47,6 +47,15 @@ __device__ __forceinline__ f32x4 lds_read4(const float* row, int off) {
     return r;
 }
 
+// Barrier that orders LDS accesses only.  __syncthreads() also waits for every outstanding global load, which ends a
+// prefetch issued in front of it.
+#define DW_LDS_BARRIER()                                    \
+    do {                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                       \
+        asm volatile("" ::: "memory");                      \
+    } while (0)
+
 // The same for the whole-row kernels, which know off % 4 from their launch arguments alone (`rem`, a scalar): when it is
 // not zero, the two aligned vectors around the four floats are read and the pick is a scalar branch.  Reads up to
 // row[(off & ~3) + 7]: those kernels' rows carry 8 floats of slack behind the last tap.
@@ -324,6 +333,22 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
     const float* mrow = norm ? a.mean + (int64_t)b * a.ssb : nullptr;
     const float* rrow = norm ? a.rstd + (int64_t)b * a.ssb : nullptr;
 
+    // The block's per-channel constants in LDS: a staged float4 belongs to a channel that differs from thread to thread,
+    // and gamma / beta fetched from global memory where they are used are a dependent round trip per staged float4
+    // -- six per phase, which is what a phase then takes.
+    constexpr int MAXCG = 16;                         // the host launches this kernel with CG <= MAXCG
+    __shared__ float pgam[MAXCG], pbet[MAXCG], pbias[MAXCG], pw[MAXCG * MAXP];
+    if (tid < MAXCG) {
+        const int c = min(c0 + tid, a.C - 1);
+        pgam[tid] = norm ? a.gamma[c] : 1.f;
+        pbet[tid] = norm ? a.beta[c] : 0.f;
+        pbias[tid] = a.bias ? a.bias[c] : 0.f;
+    }
+    if (tid < MAXCG * MAXP) {
+        const int c = c0 + tid / MAXP, k = tid % MAXP;
+        pw[tid] = (c < a.C && k < P) ? a.w[(int64_t)c * P + k] : 0.f;
+    }
+    __syncthreads();
     float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
     const int t = t0 + 4 * tid;                       // this thread's output frames
     // which staged float4s are this thread's does not depend on the channel group, and neither do the per-frame
@@ -361,8 +386,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
             const int tt = tA + 4 * i4;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             if (c < cend && tt >= 0 && tt < T) {
-                float g = 1.f, be = 0.f;
-                if (norm) g = a.gamma[c], be = a.beta[c];
+                const float g = pgam[c - c0], be = pbet[c - c0];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float u = v[j][e];
@@ -374,7 +398,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
             ctn_st4(&lds[r * lw + 4 * i4], o);
         }
         if (cg + CS < cend) load_phase(cg + CS);
-        __syncthreads();
+        DW_LDS_BARRIER();
         // ---- taps: one float4 of output per thread and channel
         if (t < t_end) {
             const int base = t - padL - tA;
@@ -382,12 +406,12 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
             for (int r = 0; r < CS; ++r) {
                 const int c = cg + r;
                 if (c >= cend) break;
-                const float bias = a.bias ? a.bias[c] : 0.f;
+                const float bias = pbias[c - c0];
                 f32x4 o = {bias, bias, bias, bias};
 #pragma unroll
                 for (int k = 0; k < MAXP; ++k) {
                     if (k < P) {
-                        const float wk = a.w[(int64_t)c * P + k];
+                        const float wk = pw[(c - c0) * MAXP + k];
                         o += wk * lds_read4(lds + r * lw, base + k * d);
                     }
                 }
@@ -402,7 +426,7 @@ __global__ __launch_bounds__(NTH) void dw_fwd_cln_kernel(const ctn_dw_fwd_args a
                 }
             }
         }
-        __syncthreads();
+        DW_LDS_BARRIER();
     }
     if (do_stats) col_atomics(lds, cs1, cs2, a.ecol + (int64_t)b * 2 * a.ecol_ld, a.ecol_ld, t0, t_end);
 }
@@ -678,10 +702,24 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
     float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
     const int t = t0 + 4 * tid;                        // this thread's output frames (one float4 per channel)
     if (tid < MAXPH * NP) chan[tid] = 0.f;             // visible after the first barrier of the loop
+    // the block's per-channel constants, fetched once: read from global memory inside the phases they are a dependent
+    // round trip in front of every phase's arithmetic
+    constexpr int MAXCG = CS * MAXPH;
+    __shared__ float pg2[MAXCG], pg1[MAXCG], pb1[MAXCG], pw[MAXCG * P];
+    if (tid < MAXCG) {
+        const int c = min(c0 + tid, a.C - 1);
+        pg2[tid] = a.gamma2[c];
+        pg1[tid] = a.gamma1[c];
+        pb1[tid] = a.beta1[c];
+    }
+    if (tid < MAXCG * P) {
+        const int c = min(c0 + tid / P, a.C - 1);
+        pw[tid] = a.w[(int64_t)c * P + tid % P];
+    }
+    __syncthreads();
 
-    // The rows of a phase are requested as soon as the previous phase has staged its own (the registers are free from
-    // then on), so they arrive under that phase's tap loops and reductions: at two blocks per CU a phase that fetches
-    // its rows where it needs them waits out the whole memory latency eight times per block.
+    // (Requesting a phase's rows one phase ahead was measured and is not done: the registers it holds across the tap
+    // loops cost the third resident block, 391 against 363 us.)
     f32x4 vdn[CS][NITB], vx[CS][NITB], vy[CS][NITB];
     auto load_phase = [&](const int cg) {
 #pragma unroll
@@ -695,15 +733,15 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
             }
         }
     };
-    if (c0 < cend) load_phase(c0);
     for (int cg = c0; cg < cend; cg += CS) {
+        load_phase(cg);
         float v[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) v[i] = 0.f;
 #pragma unroll
         for (int r = 0; r < CS; ++r) {
             const bool ch_ok = cg + r < cend;
-            const float g2 = a.gamma2[min(cg + r, cend - 1)];
+            const float g2 = pg2[min(cg + r, cend - 1) - c0];
             float* D = lds + (size_t)r * 2 * lw;
             float* Xh = D + lw;
             float dgamma2 = 0.f, dbeta2 = 0.f, dbias = 0.f;
@@ -740,7 +778,6 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
             }
             v[r * NV + 0] = dgamma2; v[r * NV + 1] = dbeta2; v[r * NV + 2] = dbias;
         }
-        if (cg + CS < cend) load_phase(cg + CS);
         __syncthreads();
         // ---- input gradient, weight gradient, norm-1 reductions
         if (t < t_end) {
@@ -751,7 +788,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
                 if (c >= cend) break;
                 const float* D = lds + (size_t)r * 2 * lw;
                 const float* Xh = D + lw;
-                const float g1 = a.gamma1[c], be1 = a.beta1[c];
+                const float g1 = pg1[c - c0], be1 = pb1[c - c0];
                 const f32x4 dy4 = ctn_ld4(&D[i0]);
                 const f32x4 xh4 = ctn_ld4(&Xh[i0]);
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -759,7 +796,7 @@ __global__ __launch_bounds__(NTH) void dw_bwd_cln_kernel(const ctn_dw_bwd_args a
                 for (int k = 0; k < P; ++k) {
                     const f32x4 dk = lds_read4(D, i0 - k * d + padL);
                     const f32x4 xk = lds_read4(Xh, i0 + k * d - padL);
-                    o += a.w[(int64_t)c * P + k] * dk;
+                    o += pw[(c - c0) * P + k] * dk;
                     float dwa = 0.f, dwb = 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {

@@ -218,8 +218,10 @@ int ctn_lstm_bwd(const float* dhout, const float* save, const float* whh, int N,
  * arith: CTN_ARITH_DEFAULT / CTN_ARITH_BF16X3 = the exact three-piece split with six bf16 matrix instructions per
  * product, as in ctn_gemm_nn; CTN_ARITH_F32 = v_mfma_f32_32x32x2_f32.  In ctn_rows_gemm the split form applies to
  * w_is_km = 0 (both operands contiguous along the contraction; a caller that wants it for a (K, M) weight passes the
- * transposed copy) and w_is_km = 1 always runs f32 instructions; ctn_rows_wgrad runs f32 instructions by default
- * (CTN_ARITH_DEFAULT: the faster form at these shapes) and the split form on explicit CTN_ARITH_BF16X3 for M > 64.
+ * transposed copy) and w_is_km = 1 always runs f32 instructions; ctn_rows_wgrad under CTN_ARITH_DEFAULT runs the
+ * split form where its whole-output kernel applies (M a multiple of 512, K a multiple of 64 up to 128, vector layout:
+ * the recurrent layers' weight gradients) and f32 instructions elsewhere; explicit CTN_ARITH_BF16X3 takes the split
+ * form for any M > 64.
  * Any R, K, M >= 1; 16-byte aligned bases and row strides that are multiples of 4 floats take the vector-load path,
  * anything else a scalar one.
  * ------------------------------------------------------------------------------------------- */

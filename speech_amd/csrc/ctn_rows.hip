@@ -627,6 +627,201 @@ __global__ __launch_bounds__(RNTH) void rows_wgrad_b3_kernel(const float* __rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ dW += dY^T X, whole output per block
+// The three-piece weight gradient for the recurrent layers' shapes (512 x 128, 512 x 64 per block): ONE block holds the
+// whole output in its accumulators (eight waves, 128 or 64 registers each) and walks a chunk of rows, so every element of
+// dY and X is fetched, split and staged exactly once on the chip, and each wave's 4 x 2 (or 2 x 2) accumulator tiles
+// reuse a fragment set 2 to 4 times: 18 KB of LDS fragments per 48 matrix instructions where the tile-per-block kernel
+// above reads 9 KB per 12.  Stages of 16 rows (one k-step of the matrix instruction), planes double-buffered, operands
+// requested two stages ahead by buffer loads whose range check supplies the zeros behind the chunk's last row; the
+// barriers order LDS traffic only.  LDS image of a plane: rows of MB bf16, as segments of 256 bytes with the chunk swizzle
+// of rows_img_off inside each segment (segments and rows alias on the banks alike, so the 256-byte analysis carries over).
+template <int WM, int WK, int NWM, int NWK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void rows_wgrad_b3_full_kernel(const float* __restrict__ dY, const int64_t lddy, const float* __restrict__ X,
+                               const int64_t ldx, const int64_t R, const int M, const int K, float* __restrict__ dW,
+                               const int64_t lddw, float* __restrict__ dbias, const float sign, const int64_t rchunk) {
+    static_assert(NWM * NWK == 8, "eight waves");
+    constexpr int NTHF = 512, RS = 16;
+    constexpr int MB = 32 * WM * NWM, KB = 32 * WK * NWK;          // the block's output: MB x KB
+    constexpr int YPITCH = 2 * MB, XPITCH = KB >= 128 ? 2 * KB : 256;   // bytes per LDS row (whole 256-byte segments)
+    constexpr int YPLANE = RS * YPITCH, XPLANE = RS * XPITCH;
+    constexpr int YBUF = 3 * YPLANE, XBUF = 3 * XPLANE;
+    constexpr int YQ = RS * (MB / 4) / NTHF;                       // float4 of dY per thread and stage
+    constexpr int XTH = RS * (KB / 4);                             // threads that carry a float4 of X
+    static_assert(YQ >= 1 && XTH <= NTHF, "tile / thread mapping");
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+    unsigned char* const Yp = wlds;                                // two buffers
+    unsigned char* const Xp = wlds + 2 * YBUF;
+    float* const csum = reinterpret_cast<float*>(wlds + 2 * YBUF + 2 * XBUF);      // [NTHF / (MB / 4)][MB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wv % NWM, wk = wv / NWM;                        // this wave's output tiles: rows 32 WM wm .., columns 32 WK wk ..
+    const int m0 = blockIdx.x * MB, k0 = blockIdx.y * KB;
+    // The row stages are dealt round-robin over the blocks (stage G of the matrix goes to block G % gridDim.z): at any
+    // moment the resident blocks read one contiguous stretch of the operands.  With a contiguous chunk per block the
+    // blocks' streams lie a chunk apart, advance in lock-step and keep landing on the same memory channels (measured:
+    // 2.4 TB/s).
+    const int64_t nstages = (R + RS - 1) / RS;
+    const int nz = gridDim.z, bz = blockIdx.z;
+    const int nst = (int)((nstages - bz + nz - 1) / nz);          // stages bz, bz + nz, ...
+
+    f32x16 acc[WM][WK];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WK; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+
+    // loaders: float4 i = tid + NTHF q of the 16 x MB tile of dY (row i / (MB / 4), columns 4 (i % (MB / 4))); X likewise
+    typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+    constexpr int YF4 = MB / 4, XF4 = KB / 4;
+    const int yrow = tid / YF4, ycol = (tid % YF4) * 4;            // + (NTHF / YF4) rows per q
+    const int xrow = tid / XF4, xcol = (tid % XF4) * 4;
+    constexpr int YRQ = NTHF / YF4;
+    const int voY = (yrow * (int)lddy + ycol) * 4, voX = (xrow * (int)ldx + xcol) * 4;
+    const int qY = YRQ * (int)lddy * 4;
+    // a stage's descriptors start at its first row and end behind its last valid one: rows beyond the matrix (the ragged
+    // last stage, and stages requested past the block's last) come back as zeros and touch no memory
+    auto fetch = [&](const int g, wu32x4 (&ry)[YQ], wu32x4& rx) {
+        const int64_t row0 = ((int64_t)g * nz + bz) * RS;
+        const int64_t left = R - row0;
+        const int rows = left >= RS ? RS : (left > 0 ? (int)left : 0);
+        const int64_t r0c = rows > 0 ? row0 : 0;
+        const auto rY = __builtin_amdgcn_make_buffer_rsrc((void*)(dY + r0c * lddy + m0), 0,
+                                                          rows > 0 ? (int)(((int64_t)(rows - 1) * lddy + MB) * 4) : 0, 0x00020000);
+        const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(X + r0c * ldx + k0), 0,
+                                                          rows > 0 ? (int)(((int64_t)(rows - 1) * ldx + KB) * 4) : 0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) ry[q] = __builtin_amdgcn_raw_buffer_load_b128(rY, voY + q * qY, 0, 0);
+        if (tid < XTH) rx = __builtin_amdgcn_raw_buffer_load_b128(rX, voX, 0, 0);
+    };
+    auto img = [](const int row, const int col, const int pitch) -> int {      // byte offset of 4 bf16 at (row, col)
+        return row * pitch + (col >> 7) * 256 + 16 * ((((col & 127) >> 3)) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + (col & 4) * 2;
+    };
+    auto stage = [&](const wu32x4 (&ry)[YQ], const wu32x4& rx, const int buf) {
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, ry[q]);
+            ru32x2 h, m, l;
+            rows_split3(v, h, m, l);
+            unsigned char* o = Yp + buf * YBUF + img(yrow + YRQ * q, ycol, YPITCH);
+            *reinterpret_cast<ru32x2*>(o) = h;
+            *reinterpret_cast<ru32x2*>(o + YPLANE) = m;
+            *reinterpret_cast<ru32x2*>(o + 2 * YPLANE) = l;
+            if (do_bias) colsum += v;
+        }
+        if (tid < XTH) {
+            ru32x2 h, m, l;
+            rows_split3(__builtin_bit_cast(f32x4, rx), h, m, l);
+            unsigned char* o = Xp + buf * XBUF + img(xrow, xcol, XPITCH);
+            *reinterpret_cast<ru32x2*>(o) = h;
+            *reinterpret_cast<ru32x2*>(o + XPLANE) = m;
+            *reinterpret_cast<ru32x2*>(o + 2 * XPLANE) = l;
+        }
+    };
+    // transposing read of one fragment: rows 8 (lane / 32) .. + 7 of the stage, column c0 + lane % 32 (c0 a multiple of 32)
+    const int gq = (lane & 15) >> 2, gp = lane & 3, gblk = ((lane >> 4) & 1) * 16, ghalf = lane >> 5;
+    auto frag = [&](const unsigned char* plane, const int c0, const int pitch) -> rbf16x8 {
+        const int col = c0 + gblk + 4 * gp;
+        union { rbf16x8 v; rs16x4 h[2]; } u;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const unsigned char* ptr = plane + img(8 * ghalf + 4 * x + gq, col, pitch);
+            u.h[x] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs16x4*)(ptr));
+        }
+        return u.v;
+    };
+    auto compute = [&](const int buf) {
+        const unsigned char* Yb = Yp + buf * YBUF;
+        const unsigned char* Xb = Xp + buf * XBUF;
+        rbf16x8 bf[WK][3];
+#pragma unroll
+        for (int j = 0; j < WK; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[j][pl] = frag(Xb + pl * XPLANE, 32 * (WK * wk + j), XPITCH);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            rbf16x8 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[pl] = frag(Yb + pl * YPLANE, 32 * (WM * wm + i), YPITCH);
+            // smallest products first; the k-tiles alternate so that consecutive instructions are independent
+#define ROWS_W_MFMA(a_, b_)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < WK; ++j)                                                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a_], bf[j][b_], acc[i][j], 0, 0, 0)
+            ROWS_W_MFMA(2, 0);
+            ROWS_W_MFMA(0, 2);
+            ROWS_W_MFMA(1, 1);
+            ROWS_W_MFMA(1, 0);
+            ROWS_W_MFMA(0, 1);
+            ROWS_W_MFMA(0, 0);
+#undef ROWS_W_MFMA
+        }
+    };
+#define ROWS_LDS_BARRIER()                                  \
+    do {                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                       \
+        asm volatile("" ::: "memory");                      \
+    } while (0)
+
+    if (nst > 0) {
+        // stage g: [barrier] request stage g + 2 -> matrix instructions of g (buffer g & 1) -> split and store g + 1
+        wu32x4 ry0[YQ], ry1[YQ], rx0 = {0, 0, 0, 0}, rx1 = {0, 0, 0, 0};
+        fetch(0, ry0, rx0);
+        fetch(1, ry1, rx1);                            // beyond the chunk: zeros
+        stage(ry0, rx0, 0);
+        for (int g = 0; g < nst; g += 2) {
+            ROWS_LDS_BARRIER();
+            fetch(g + 2, ry0, rx0);
+            compute(0);
+            stage(ry1, rx1, 1);                        // stage g + 1 (zeros behind the chunk's end: harmless)
+            ROWS_LDS_BARRIER();
+            fetch(g + 3, ry1, rx1);
+            if (g + 1 < nst) compute(1);
+            stage(ry0, rx0, 0);
+        }
+    }
+#undef ROWS_LDS_BARRIER
+
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WK; ++j) {
+            const int k = k0 + 32 * (WK * wk + j) + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * (WM * wm + i) + (e & 3) + 8 * (e >> 2) + 4 * half;
+                atomicAdd(dW + (int64_t)m * lddw + k, sign * acc[i][j][e]);
+            }
+        }
+    if (do_bias) {          // a thread summed columns ycol .. ycol + 3 over its rows: fold the row groups through LDS
+        __syncthreads();    // the planes are no longer read; csum lies behind them
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[yrow * MB + ycol + e] = colsum[e];
+        __syncthreads();
+        if (tid < MB) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < YRQ; ++q) t += csum[q * MB + tid];
+            atomicAdd(dbias + m0 + tid, sign * t);
+        }
+    }
+}
+
+template <int WM, int WK, int NWM, int NWK>
+constexpr size_t rows_wgrad_full_lds() {
+    return (size_t)2 * 3 * 16 * 2 * (32 * WM * NWM) + (size_t)2 * 3 * 16 * (32 * WK * NWK >= 128 ? 2 * 32 * WK * NWK : 256) +
+           (size_t)(512 / (32 * WM * NWM / 4)) * (32 * WM * NWM) * 4;
+}
+
 }  // namespace
 
 extern "C" int ctn_rows_gemm(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_is_km, const float* bias,
@@ -686,6 +881,45 @@ extern "C" int ctn_rows_wgrad(const float* dY, int64_t lddy, const float* X, int
     // shapes it is the slower of the two -- 1024 x 64 over 511 104 rows: 850 against 780 us, 512 x 128: 772 against 686 --
     // because with a 32-row stage between two barriers its 24 matrix instructions per wave (768 cycles) no longer cover
     // the split, the LDS traffic and the barriers, which the f32 form's 32 instructions (2048 cycles) do.
+    // whole-output blocks for the recurrent layers' shapes: M a multiple of 512, K a multiple of 64 up to 128 per block
+    // (also what CTN_ARITH_DEFAULT means at these shapes: 405 against 655 us and 539 against 841 us over 511 104 rows)
+    if (arith != CTN_ARITH_F32 && M % 512 == 0 && K % 64 == 0 && K <= 128 && yvec && xvec && lddy < (1 << 20) &&
+        ldx < (1 << 20)) {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+            return n;
+        }();
+        const int tiles_m = M / 512;
+        // one block per CU, all resident at once; the 16-row stages are dealt round-robin over them
+        int64_t nchunks = cus / tiles_m;
+        if (nchunks < 1) nchunks = 1;
+        const int64_t nstages = (R + 15) / 16;
+        if (nchunks > (nstages + 3) / 4) nchunks = (nstages + 3) / 4;     // at least four stages per block
+        const int64_t rchunk = 0;
+        if (nchunks <= 65535) {
+            dim3 grid(tiles_m, 1, (unsigned)nchunks);
+            if (K > 64) {
+                constexpr size_t shm = rows_wgrad_full_lds<4, 2, 4, 2>();
+                const void* fn = reinterpret_cast<const void*>(&rows_wgrad_b3_full_kernel<4, 2, 4, 2>);
+                CTN_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess,
+                            "ctn_rows_wgrad: cannot raise the dynamic LDS limit");
+                hipLaunchKernelGGL((rows_wgrad_b3_full_kernel<4, 2, 4, 2>), grid, dim3(512), shm, (hipStream_t)stream, dY, lddy,
+                                   X, ldx, R, M, K, dW, lddw, dbias, sign, rchunk);
+            } else {
+                constexpr size_t shm = rows_wgrad_full_lds<2, 2, 8, 1>();
+                const void* fn = reinterpret_cast<const void*>(&rows_wgrad_b3_full_kernel<2, 2, 8, 1>);
+                CTN_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess,
+                            "ctn_rows_wgrad: cannot raise the dynamic LDS limit");
+                hipLaunchKernelGGL((rows_wgrad_b3_full_kernel<2, 2, 8, 1>), grid, dim3(512), shm, (hipStream_t)stream, dY, lddy,
+                                   X, ldx, R, M, K, dW, lddw, dbias, sign, rchunk);
+            }
+            CTN_CHECK_LAUNCH("ctn_rows_wgrad");
+            return CTN_OK;
+        }
+    }
     const bool b3 = arith == CTN_ARITH_BF16X3 && M > 64;
     const int TM = M > 64 ? 128 : 64;
     const int tiles = ctn_cdiv(M, TM) * ctn_cdiv(K, 64);

@@ -353,7 +353,7 @@ def rows_wgrad(dy, x, dW=None, dbias=None, sign=1.0, arith=None):
         assert dbias.dtype == torch.float32 and dbias.numel() == M and dbias.is_contiguous()
     if R == 0:
         return dW
-    arith = _lib.ARITH_DEFAULT if arith is None else arith        # default: f32 matrix instructions, the faster form here
+    arith = _lib.ARITH_DEFAULT if arith is None else arith        # default: the library picks the faster form per shape
     _lib.check(lib.ctn_rows_wgrad(_ptr(dy), _ld(dy), _ptr(x), _ld(x), R, M, K, _ptr(dW), _ld(dW), _ptr(dbias), float(sign),
                                   arith, _stream()), "ctn_rows_wgrad")
     return dW

@@ -14,7 +14,7 @@ DEV = "cuda:0"
 TOL = 2e-5
 
 SHAPES = [(1000, 64, 1024), (4100, 256, 64), (777, 1024, 64), (130, 12, 400), (5, 3, 7), (1, 64, 64), (257, 100, 33),
-          (33, 128, 512)]
+          (33, 128, 512), (5000, 128, 512), (4099, 64, 1024), (70000, 64, 512), (16, 128, 512)]
 
 
 @pytest.mark.parametrize("R,K,M", SHAPES)
@@ -71,6 +71,27 @@ def test_rows_products_on_strided_and_unaligned_views():
     assert x.data_ptr() % 16 != 0
     assert_close(ops.rows_gemm(x, w), x.double() @ w.double().t(), TOL, "unaligned gemm")
     assert_close(ops.rows_wgrad(x, x), x.double().t() @ x.double(), TOL, "unaligned wgrad")
+
+
+def test_whole_output_weight_gradient_on_strided_views():
+    """The whole-output three-piece kernel (M a multiple of 512, K 64 or 128) on the views LstmFn.backward passes: one
+    direction's columns of (rows, directions, 4H) gate gradients, shifted by a row, with the subtracting form."""
+    from speech_amd import ops, _lib
+    N, T, D, H = 37, 61, 2, 128
+    dg = synth.normal((N, T, D, 4 * H), 16).to(DEV)
+    h = synth.normal((N, T, D, H), 17).to(DEV)
+    x = synth.normal((N * T, 64), 18).to(DEV)
+    for d in range(D):
+        a, b = dg.view(N * T, D, 4 * H)[:, d][1:], h.view(N * T, D, H)[:, d][:-1]
+        ref = a.double().t() @ b.double()
+        dW = ops.rows_wgrad(a, b, arith=_lib.ARITH_BF16X3)
+        assert_close(dW, ref, TOL, "recurrent weights, direction %d" % d)
+        ops.rows_wgrad(a, b, dW=dW, sign=-1.0, arith=_lib.ARITH_BF16X3)
+        assert float(dW.abs().max()) <= 1e-5 * float(ref.abs().max())
+    a = dg.view(N * T, D * 4 * H)
+    db = torch.zeros(D * 4 * H, device=DEV)
+    assert_close(ops.rows_wgrad(a, x, dbias=db, arith=_lib.ARITH_BF16X3), a.double().t() @ x.double(), TOL, "input weights")
+    assert_close(db, a.double().sum(0), TOL, "bias")
 
 
 def test_linear_fn_matches_float64():

@@ -412,7 +412,9 @@ __global__ __launch_bounds__(RNTH) void rows_wgrad_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TK;
-    const int64_t rb = (int64_t)blockIdx.z * rchunk, re = rb + rchunk < R ? rb + rchunk : R;
+    // the 32-row stages are dealt round-robin over the grid's z blocks (stage G to block G % gridDim.z), so that the
+    // resident blocks read one contiguous stretch of the operands at a time instead of streams a chunk apart
+    const int64_t re = R, rstep = (int64_t)gridDim.z * RS, rb = (int64_t)blockIdx.z * RS;
     const int wm = TM == 128 ? wave * 32 : (wave >> 1) * 32;
     const int wk = TM == 128 ? 0 : (wave & 1) * 32;
 
@@ -445,13 +447,13 @@ __global__ __launch_bounds__(RNTH) void rows_wgrad_kernel(const float* __restric
 
     if (rb < re) {
         fetch(rb);
-        for (int64_t rs = rb; rs < re; rs += RS) {
+        for (int64_t rs = rb; rs < re; rs += rstep) {
 #pragma unroll
             for (int q = 0; q < NY; ++q) ctn_st4(&Ys[(tid + RNTH * q) * 4], ry[q]);
 #pragma unroll
             for (int q = 0; q < NX; ++q) ctn_st4(&Xs[(tid + RNTH * q) * 4], rx[q]);
             __syncthreads();
-            if (rs + RS < re) fetch(rs + RS);
+            if (rs + rstep < re) fetch(rs + rstep);
 #pragma unroll
             for (int s = 0; s < RS / 2; ++s) {
                 const int rr = 2 * s + half;

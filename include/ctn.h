@@ -373,6 +373,12 @@ typedef struct {
 
 int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream);
 
+/* Number of ctn_gemm_nt calls of this process that ran the whole-output kernels (one 512-thread block keeps a
+ * 256 x 256 or 256 x 128 output in its accumulators; chosen only when CTN_NT_WHOLE=1 is set in the environment and the
+ * call has the shape of the residual layer's heads or bottleneck weight gradient).  A diagnostic for tests and
+ * benchmarks that must know which kernels they measured; no counterpart in the reference. */
+int64_t ctn_gemm_nt_whole_launches(void);
+
 /* The backward coefficients of the global layer norm in front of the residual layer's heads, WITHOUT a pass over the
  * normalised tensor: with dn = W^T dY (the heads' input gradient) and the heads' weight gradient computed per batch
  * element as G'_b[m][c] = sum_t dY_b[m][t] gamma_c xhat_b[c][t] (ctn_gemm_nt with b_beta = 0),

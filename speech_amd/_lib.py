@@ -183,6 +183,7 @@ PROTOTYPES = {
     "ctn_lstm_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "ctn_gemm_nn": (C.c_int, [C.POINTER(GemmNNArgs), _p]),
     "ctn_gemm_nt": (C.c_int, [C.POINTER(GemmNTArgs), _p]),
+    "ctn_gemm_nt_whole_launches": (C.c_int64, []),
     "ctn_norm_stats": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _i64, _p, _p, _p, _i64, _p]),
     "ctn_gln_finalize": (C.c_int, [_p, C.c_int, _f64, _f32, _p, _p, _p]),
     "ctn_cln_finalize": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _i64, _f32, _p, _p, _i64, _p]),

@@ -899,6 +899,9 @@ bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
 
 }  // namespace
 
+// whole-output kernels for the residual layer's two weight-gradient shapes (ctn_gemm_nt_whole.hip)
+int ctn_gemm_nt_whole_try(const ctn_gemm_nt_args& a, hipStream_t s);
+
 extern "C" int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream) {
     CTN_REQUIRE(args, "ctn_gemm_nt: null args");
     const ctn_gemm_nt_args& a = *args;
@@ -922,6 +925,10 @@ extern "C" int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream) {
         CTN_REQUIRE(!a.wdot_sums || ((a.M1 == 0 || a.wdot) && (a.M1 == a.M || a.wdot2)), "ctn_gemm_nt: wdot_sums needs wdot / wdot2");
     }
     hipStream_t s = (hipStream_t)stream;
+    if (ctn_gemm_nt_whole_try(a, s)) {
+        CTN_CHECK_LAUNCH("ctn_gemm_nt");
+        return CTN_OK;
+    }
     if (fast_ok(a))
         launch_fast(a, s);
     else if (a.M > 64 && a.N > 64)

@@ -378,7 +378,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch every kernel eagerly instead of replaying the forward/backward pass from a HIP graph")
-    ap.add_argument("--streams", type=int, default=2, help="sub-batches of a rank's shard run on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="sub-batches of a rank's shard run on separate HIP streams (1: the whole shard in one pass, "
+                         "which is what the whole-output weight-gradient kernels are fastest at)")
     ap.add_argument("--buckets", type=int, default=4,
                     help="pieces of the flat gradient buffer all-reduced concurrently behind the pass (more than one rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

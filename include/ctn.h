@@ -369,14 +369,26 @@ typedef struct {
     const float* wdot;  int64_t ldwd;
     const float* wdot2; int64_t ldwd2;
     double* wdot_sums;
+    /* Optional workspace of the whole-output kernels (below): ws_floats floats, 16-byte aligned, contents irrelevant
+     * before and after the call, not shared with a call that may run at the same time.  ctn_gemm_nt_ws_floats says how
+     * many floats a call would use; NULL or too small: the kernels add their partial outputs with float atomics. */
+    float* ws; int64_t ws_floats;
 } ctn_gemm_nt_args;
 
 int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream);
 
-/* Number of ctn_gemm_nt calls of this process that ran the whole-output kernels (one 512-thread block keeps a
- * 256 x 256 or 256 x 128 output in its accumulators; chosen only when CTN_NT_WHOLE=1 is set in the environment and the
- * call has the shape of the residual layer's heads or bottleneck weight gradient).  A diagnostic for tests and
- * benchmarks that must know which kernels they measured; no counterpart in the reference. */
+/* The whole-output kernels of ctn_gemm_nt: for the two weight-gradient shapes of a residual layer (M = 256 against N a
+ * multiple of 256; the NORMBWD operand with M a multiple of 256 against N = 128), three-piece arithmetic, global norm
+ * statistics and enough frames to give every CU four to eight stages, one 512-thread block per CU keeps a 256 x 256 or
+ * 256 x 128 output in its accumulators and every operand element is fetched, transformed and split once.  With a
+ * workspace (fields ws / ws_floats) the blocks store their partial outputs and a second launch adds them in a fixed
+ * order -- C and the row sums then get the same bits on every run -- instead of 16.8 M float atomics.
+ * CTN_NT_WHOLE in the environment (read at every call): 0 = tile kernels only, 2 = the NORMBWD form only, 3 = the other
+ * form only.  No counterpart in the reference (autograd of nn.Conv1d, src/models/tdcn.py:118-120,172-175).
+ *   ctn_gemm_nt_ws_floats:      floats of workspace the call described by args would use (0: it takes the tile kernels)
+ *   ctn_gemm_nt_whole_launches: calls of this process that took the whole-output kernels (a diagnostic for tests and
+ *                               benchmarks that must know which kernels they measured) */
+int64_t ctn_gemm_nt_ws_floats(const ctn_gemm_nt_args* args);
 int64_t ctn_gemm_nt_whole_launches(void);
 
 /* The backward coefficients of the global layer norm in front of the residual layer's heads, WITHOUT a pass over the

@@ -92,6 +92,7 @@ class GemmNTArgs(C.Structure):
         ("b_gamma", _p), ("b_beta", _p),
         ("C", _p), ("ldc", _i64), ("C2", _p), ("ldc2", _i64),
         ("a_rowsum_b", _p), ("wdot", _p), ("ldwd", _i64), ("wdot2", _p), ("ldwd2", _i64), ("wdot_sums", _p),
+        ("ws", _p), ("ws_floats", _i64),
     ]
 
 
@@ -184,6 +185,7 @@ PROTOTYPES = {
     "ctn_gemm_nn": (C.c_int, [C.POINTER(GemmNNArgs), _p]),
     "ctn_gemm_nt": (C.c_int, [C.POINTER(GemmNTArgs), _p]),
     "ctn_gemm_nt_whole_launches": (C.c_int64, []),
+    "ctn_gemm_nt_ws_floats": (C.c_int64, [C.POINTER(GemmNTArgs)]),
     "ctn_norm_stats": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _i64, _p, _p, _p, _i64, _p]),
     "ctn_gln_finalize": (C.c_int, [_p, C.c_int, _f64, _f32, _p, _p, _p]),
     "ctn_cln_finalize": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _i64, _f32, _p, _p, _i64, _p]),

@@ -837,7 +837,10 @@ bool stat_rows(const ctn_gemm_nt_args& a) {
     return ((a.aflags & CTN_XF_NORMBWD) && a.a_sst == 1) || ((a.bflags & CTN_XF_NORM) && a.b_sst == 1);
 }
 
-template <int TM, int TN, bool BWD, int BXF, int FK = (BWD ? 16 : 32), bool KS = false>
+#ifndef CTN_NT_BWD_FK
+#define CTN_NT_BWD_FK 16
+#endif
+template <int TM, int TN, bool BWD, int BXF, int FK = (BWD ? CTN_NT_BWD_FK : 32), bool KS = false>
 void launch_fast_x(const ctn_gemm_nt_args& a, hipStream_t s) {
     const int tiles_m = ctn_cdiv(a.M, TM), tiles_n = ctn_cdiv(a.N, TN);
     const int nchunks = ctn_cdiv(a.T, a.kchunk);
@@ -900,7 +903,7 @@ bool act_ok(const float* p, int64_t ld, int64_t bs, int T) {
 }  // namespace
 
 // whole-output kernels for the residual layer's two weight-gradient shapes (ctn_gemm_nt_whole.hip)
-int ctn_gemm_nt_whole_try(const ctn_gemm_nt_args& a, hipStream_t s);
+int ctn_gemm_nt_whole_try(const ctn_gemm_nt_args& a, hipStream_t s, int64_t* ws_query);
 
 extern "C" int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream) {
     CTN_REQUIRE(args, "ctn_gemm_nt: null args");
@@ -925,7 +928,7 @@ extern "C" int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream) {
         CTN_REQUIRE(!a.wdot_sums || ((a.M1 == 0 || a.wdot) && (a.M1 == a.M || a.wdot2)), "ctn_gemm_nt: wdot_sums needs wdot / wdot2");
     }
     hipStream_t s = (hipStream_t)stream;
-    if (ctn_gemm_nt_whole_try(a, s)) {
+    if (ctn_gemm_nt_whole_try(a, s, nullptr)) {
         CTN_CHECK_LAUNCH("ctn_gemm_nt");
         return CTN_OK;
     }

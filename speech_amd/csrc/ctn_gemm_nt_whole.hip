@@ -19,19 +19,24 @@
 // and the PReLU-slope gradient of the norm-backward operand are formed by the staging threads, which see every element
 // of A exactly once.
 //
-// OFF unless CTN_NT_WHOLE=1 is set: measured on MI355X over 32 x 3999 frames (16 x 3999 in brackets), it does not beat
-// the tile kernels where the training step calls them -- heads 279 us against 291 (166 against 136), bottleneck 191
-// against 191 (110 against 104); the step as a whole ran at 890 against 929 utterances/s with an earlier version on.
-// Cycle stamps of one block (-DWH_TRACE, tools/trace_nt_whole.py) say why.  (1) A quarter of the heads kernel is its
-// epilogue: every CU holds a full-size partial output (256 KB), the 256 partials meet in 16.8 M float atomics, and with
-// one block per CU nothing else runs beneath them; the tile kernels' smaller blocks end at different times and hide
-// theirs.  The cost is per launch, so it doubles in weight when the step halves the batch per launch.  (2) The main
-// loop reaches 4500 cycles per 16-frame stage against 3072 of matrix instructions: a wave on its own issues one every
-// 52 - 55 cycles, not 32 (fragment reads between them), and the two waves of a SIMD overlap for part of a stage only.
-// (3) The bottleneck form is bound by its conversions (2 x 1750 cycles of vector work per 32-frame stage and SIMD
-// against 3072 of matrix work) and spills 17 registers in the loop.  16-frame stages of it were slower still: 64
-// contiguous bytes per row and request reach 3.3 TB/s at most on this memory system, 128 bytes and more reach 6.7
-// (tools/probe/rowseg_read.hip).
+// With a workspace from the caller the blocks store their partial outputs (fragment order, 256-byte stores) and a
+// second launch adds the 128 partials of each element in a fixed order: 211 + 15 us where the atomics route takes 257
+// (every CU ends with a full-size partial, 256 KB, and 16.8 M float atomics at about one per clock and L2 channel have
+// nothing running beneath them with one block per CU), and the same bits in C on every run.
+//
+// Measured on MI355X over 32 x 3999 frames (16 x 3999 in brackets), launch to launch: heads 239 us against 291 for the
+// tile kernels (113 against 134), bottleneck 163 against 191 (94 against 104); the training step 943.6 -> 979.5
+// utterances/s on one stream.  How it got there, from cycle stamps of one block (-DWH_TRACE, tools/trace_nt_whole.py):
+// a first version (all waves in one order, 16-frame stages in both forms, two accumulation chains, atomics) ran at
+// 282 / 235 us.  (1) 16-frame stages read 64 contiguous bytes per row and request, which this memory system serves at
+// 3.3 TB/s at most against 6.7 for 128 bytes and more (tools/probe/rowseg_read.hip): the bottleneck form, three input
+// streams, was at that limit, 32-frame stages took it to 191.  (2) The two loop bodies unrolled over the buffer pair
+// kept two stages' registers live in the second wave order and spilled 17 registers, whose reloads wait on the
+// prefetch in flight; one body with a run-time buffer index: 208 registers, 166 us.  (3) The wave orders, four
+// accumulation chains and the request position were then set per form by measurement (see the loop).  What remains: a
+// wave on its own issues a matrix instruction every 52 - 70 cycles, not 32 (fragment reads in between), the bottleneck
+// form's conversions (2 x 1750 cycles of vector work per stage and SIMD against 3072 of matrix work) bound it, and
+// the stored partials still cost 15 - 20 % of a launch.
 #include <stdlib.h>
 
 #include <atomic>
@@ -77,6 +82,18 @@ typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 // which waves run a stage's two halves in the other order (0: none; 1: waves 4..7; 2: odd waves)
+#ifndef WH_IP_BWD
+#define WH_IP_BWD 1
+#endif
+#ifndef WH_IP_HEADS
+#define WH_IP_HEADS 2
+#endif
+#ifndef WH_AORDER_BWD
+#define WH_AORDER_BWD 0
+#endif
+#ifndef WH_AORDER_HEADS
+#define WH_AORDER_HEADS 1
+#endif
 #ifndef WH_SHIFT
 #define WH_SHIFT 1
 #endif
@@ -110,14 +127,16 @@ __device__ __forceinline__ void wh_split3(const f32x4 v, wu32x2& hi, wu32x2& mid
 // the heads' gradient.  NWM x NWN waves, each WM x WN output tiles of 32 x 32; FR frames per stage (16 or 32).
 template <bool BWD, int FR, int WM, int WN, int NWM, int NWN>
 __global__ __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_nt_whole_kernel(const ctn_gemm_nt_args a) {
-    static_assert(NWM * NWN == 8, "eight waves");
+void gemm_nt_whole_kernel(const ctn_gemm_nt_args a, const bool ws_ok) {
+    static_assert(NWM * NWN == 8 && WM % 2 == 0, "eight waves, row tiles in pairs");
     static_assert(FR == 16 || FR == 32, "one or two k-steps per stage");
     constexpr int MB = 32 * WM * NWM, NB = 32 * WN * NWN;          // the block's output
     constexpr int RB = 2 * FR;                                     // bytes of a plane row
     constexpr int CH = FR / 8;                                     // 16-byte chunks of a plane row
     constexpr int SWS = CH == 2 ? 3 : 2;                           // chunk c of row r lives at chunk c ^ ((r >> SWS) % CH)
     constexpr int KS = FR / 16;                                    // k-steps of a stage
+    constexpr int IP = (BWD ? WH_IP_BWD : WH_IP_HEADS);            // row tiles whose accumulations alternate
+    constexpr bool LATE = (BWD ? WH_AORDER_BWD : WH_AORDER_HEADS) != 0;   // first half of the waves: request at the end of a step
     constexpr int PPR = FR / 4;                                    // float4 pieces of a row and stage
     constexpr int RPP = WNT / PPR;                                 // rows of one staging pass
     constexpr int APLANE = MB * RB, BPLANE = NB * RB;              // bytes of one piece plane of a stage
@@ -307,14 +326,19 @@ void gemm_nt_whole_kernel(const ctn_gemm_nt_args a) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const wbf16x8*>(Bb_ + pl * BPLANE + j * 32 * RB);
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                wbf16x8 af[3];
+            for (int i0 = 0; i0 < WM; i0 += IP) {
+                wbf16x8 af[IP][3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const wbf16x8*>(Ab_ + pl * APLANE + i * 32 * RB);
-                // smallest products first; the column tiles alternate so that consecutive instructions are independent
-#define WH_MFMA(a_, b_)                                                                             \
-    _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                  \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a_], bf[j][b_], acc[i][j], 0, 0, 0)
+                for (int ii = 0; ii < IP; ++ii)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[ii][pl] = *reinterpret_cast<const wbf16x8*>(Ab_ + pl * APLANE + (i0 + ii) * 32 * RB);
+                // smallest products first; the tiles of two rows alternate so that four independent accumulations are
+                // in flight (a wave on its own otherwise waits on each instruction's predecessor in its chain)
+#define WH_MFMA(a_, b_)                                                                                   \
+    _Pragma("unroll") for (int ii = 0; ii < IP; ++ii)                                                     \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                    \
+            acc[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][a_], bf[j][b_], acc[i0 + ii][j], 0, 0, 0)
                 WH_MFMA(2, 0);
                 WH_MFMA(0, 2);
                 WH_MFMA(1, 1);
@@ -327,74 +351,89 @@ void gemm_nt_whole_kernel(const ctn_gemm_nt_args a) {
     };
 
     if (nst > 0) {
-        // step g: [barrier] request stage g + 1 -> matrix instructions of g (buffer g & 1) -> transform, split, store g + 1.
-        // The second half of the waves does the same work in the other order (store g + 1, request g + 2, matrix
-        // instructions of g), so that on each SIMD one wave's conversions run under the other's matrix instructions.
+        // step g: [barrier] matrix instructions of g (buffer g & 1) -> transform, split, store g + 1, with the request
+        // for g + 1 in front of the matrix instructions or (LATE) the one for g + 2 behind the stores.  The second half
+        // of the waves does the same work in the other order (store g + 1, request g + 2, matrix instructions of g), so
+        // that on each SIMD one wave's conversions run under the other's matrix instructions.  Which request position
+        // and how many alternating accumulation chains is measured per form: heads 275 us (early, two chains) -> 257
+        // (late, four); bottleneck 163 us (early, two) -> 185 (late, four).
         Stage s0, s1;
         fetch(0, s0);
         stage(s0, 0);
         if (!WH_SHIFTED(wv)) {
-            for (int g = 0; g < nst; g += 2) {
-                WH_BARRIER();
-                WH_STAMP();
-                fetch(g + 1, s1);
-                compute(0);
-                WH_STAMP();
-                WH_WAITV();
-                WH_STAMP();
-                stage(s1, 1);                            // behind the block's last stage: all zeros, never multiplied
-                WH_STAMP();
-                WH_BARRIER();
-                WH_STAMP();
-                fetch(g + 2, s0);
-                if (g + 1 < nst) compute(1);
-                WH_STAMP();
-                WH_WAITV();
-                WH_STAMP();
-                stage(s0, 0);
-                WH_STAMP();
+            if (LATE) {
+                fetch(1, s1);
+                for (int g = 0; g < nst; ++g) {
+                    const int buf = g & 1;
+                    WH_BARRIER();
+                    WH_STAMP();
+                    compute(buf);
+                    WH_STAMP();
+                    WH_WAITV();
+                    WH_STAMP();
+                    stage(s1, buf ^ 1);                  // behind the block's last stage: all zeros, never multiplied
+                    WH_STAMP();
+                    __builtin_amdgcn_sched_barrier(0);           // the requests reuse the registers just stored
+                    fetch(g + 2, s1);
+                }
+            } else {
+                for (int g = 0; g < nst; ++g) {
+                    const int buf = g & 1;
+                    WH_BARRIER();
+                    WH_STAMP();
+                    fetch(g + 1, s1);
+                    compute(buf);
+                    WH_STAMP();
+                    WH_WAITV();
+                    WH_STAMP();
+                    stage(s1, buf ^ 1);
+                    WH_STAMP();
+                }
             }
         } else {
             fetch(1, s0);
-            for (int g = 0; g < nst; g += 2) {
+            for (int g = 0; g < nst; ++g) {
+                const int buf = g & 1;
                 WH_BARRIER();
                 WH_STAMP();
                 WH_WAITV();
                 WH_STAMP();
-                stage(s0, 1);
+                stage(s0, buf ^ 1);
                 WH_STAMP();
                 __builtin_amdgcn_sched_barrier(0);               // the requests reuse the registers just stored
                 fetch(g + 2, s0);
-                compute(0);
-                WH_STAMP();
-                WH_BARRIER();
-                WH_STAMP();
-                WH_WAITV();
-                WH_STAMP();
-                stage(s0, 0);
-                WH_STAMP();
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(g + 3, s0);
-                if (g + 1 < nst) compute(1);
+                compute(buf);
                 WH_STAMP();
             }
         }
     }
     WH_STAMP();
 
-    // ---- partial output -> C
+    // ---- partial output: to the workspace in fragment order (64 consecutive floats per store; the reduction kernel
+    // below adds the blocks' partials in a fixed order), or with float atomics straight into C
+    constexpr int64_t PS = (int64_t)MB * NB + MB;                 // floats of one block's partial: tile, then row sums
+    float* const wsb = ws_ok ? a.ws + ((int64_t)bz * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * PS : nullptr;
+    if (wsb != nullptr) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = n0 + 32 * (WN * wn + j) + l31;
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + 32 * (WM * wm + i) + (e & 3) + 8 * (e >> 2) + 4 * half;
-                float* p = (m < M1) ? a.C + (int64_t)m * a.ldc + n : a.C2 + (int64_t)(m - M1) * a.ldc2 + n;
-                atomicAdd(p, acc[i][j][e]);
+                for (int e = 0; e < 16; ++e) wsb[(((wv * WM + i) * WN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + 32 * (WN * wn + j) + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + 32 * (WM * wm + i) + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    float* p = (m < M1) ? a.C + (int64_t)m * a.ldc + n : a.C2 + (int64_t)(m - M1) * a.ldc2 + n;
+                    atomicAdd(p, acc[i][j][e]);
+                }
             }
-        }
+    }
     // ---- A-side sums: the PPR threads of a row hold its pieces
     if (reducer && (a.a_rowsum != nullptr || a.a_rowsum2 != nullptr)) {
 #pragma unroll
@@ -404,7 +443,9 @@ void gemm_nt_whole_kernel(const ctn_gemm_nt_args a) {
             for (int d = 1; d < PPR; d <<= 1) sv += __shfl_xor(sv, d);
             const int m = m0 + srow + RPP * q;
             if (sfq == 0) {
-                if (m < M1) {
+                if (wsb != nullptr) {
+                    wsb[(int64_t)MB * NB + srow + RPP * q] = sv;
+                } else if (m < M1) {
                     if (a.a_rowsum) atomicAdd(a.a_rowsum + m, sv);
                 } else if (a.a_rowsum2) {
                     atomicAdd(a.a_rowsum2 + (m - M1), sv);
@@ -425,19 +466,105 @@ void gemm_nt_whole_kernel(const ctn_gemm_nt_args a) {
 #endif
 }
 
-template <bool BWD, int FR, int WM, int WN, int NWM, int NWN>
-int launch_whole(const ctn_gemm_nt_args& a, hipStream_t s, int cus) {
+// Adds the nz partial outputs of every tile in a fixed order -- four threads take a quarter of the partials each, in
+// the order of the blocks' indices, and the quarters are added in order -- and the sum to C (one float atomic per
+// output element: another launch may be adding to the same weight gradient from another stream).  A block takes 256
+// consecutive elements of the partials' fragment order as 64 float4; the last MB / 64 blocks of a tile take its row sums.
+template <int WM, int WN, int NWM, int NWN>
+__global__ __launch_bounds__(256) void gemm_nt_whole_reduce_kernel(const ctn_gemm_nt_args a, const int nz, const int tiles_m,
+                                                                   const int tiles) {
     constexpr int MB = 32 * WM * NWM, NB = 32 * WN * NWN;
-    constexpr size_t shm = (size_t)2 * 3 * 2 * FR * (MB + NB);
+    constexpr int64_t PS = (int64_t)MB * NB + MB;
+    constexpr int NBLK = MB * NB / 256;
+    __shared__ float part[4][256];
+    const int tile = blockIdx.y, tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * MB, n0 = tn * NB;
+    const float* src = a.ws + (int64_t)tile * PS;
+    const int64_t zs = (int64_t)tiles * PS;
+    const int tid = threadIdx.x, zg = tid >> 6, l = tid & 63;
+    const int zper = (nz + 3) / 4, z0 = zg * zper, z1 = min(z0 + zper, nz);
+    if (blockIdx.x < NBLK) {
+        const float* sp = src + blockIdx.x * 256 + l * 4;
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ctn_ld4(sp + (z + u) * zs);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv += v[u];
+        }
+        for (; z < z1; ++z) sv += ctn_ld4(sp + z * zs);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) part[zg][l * 4 + c] = sv[c];
+        __syncthreads();
+        const float tot = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+        const int p = blockIdx.x * 256 + tid;
+        const int lane = p & 63, e = (p >> 6) & 15, t = p >> 10;
+        const int j = t % WN, i = (t / WN) % WM, wave = t / (WN * WM);
+        const int wm = wave % NWM, wn = wave / NWM;
+        const int m = m0 + 32 * (WM * wm + i) + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int n = n0 + 32 * (WN * wn + j) + (lane & 31);
+        float* dst = (m < a.M1) ? a.C + (int64_t)m * a.ldc + n : a.C2 + (int64_t)(m - a.M1) * a.ldc2 + n;
+        atomicAdd(dst, tot);
+    } else if (tn == 0) {
+        const int r = (blockIdx.x - NBLK) * 64 + l;               // row of the tile
+        const float* sp = src + (int64_t)MB * NB + r;
+        float sv = 0.f;
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sp[(z + u) * zs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv += v[u];
+        }
+        for (; z < z1; ++z) sv += sp[z * zs];
+        part[zg][l] = sv;
+        __syncthreads();
+        if (zg == 0) {
+            const float tot = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+            const int m = m0 + r;
+            if (m < a.M1) {
+                if (a.a_rowsum) atomicAdd(a.a_rowsum + m, tot);
+            } else if (a.a_rowsum2) {
+                atomicAdd(a.a_rowsum2 + (m - a.M1), tot);
+            }
+        }
+    }
+}
+
+// blocks along the (batch, time) axis of a launch, and the floats of workspace that lets them store their partials
+template <int FR, int MB, int NB>
+int64_t whole_nz(const ctn_gemm_nt_args& a, int cus, int64_t* ws_floats) {
     const int tiles = (a.M / MB) * (a.N / NB);
     const int64_t nstages = (int64_t)a.batch * ((a.T + FR - 1) / FR);
     int64_t nz = cus / tiles;                               // one block per CU, all resident at once
     if (nz < 1) nz = 1;
     if (nz > (nstages + 3) / 4) nz = (nstages + 3) / 4;       // at least four stages per block
     if (nz > 65535) nz = 65535;
+    *ws_floats = nz * tiles * ((int64_t)MB * NB + MB);
+    return nz;
+}
+
+template <bool BWD, int FR, int WM, int WN, int NWM, int NWN>
+int launch_whole(const ctn_gemm_nt_args& a, hipStream_t s, int cus, int64_t* ws_query) {
+    constexpr int MB = 32 * WM * NWM, NB = 32 * WN * NWN;
+    constexpr size_t shm = (size_t)2 * 3 * 2 * FR * (MB + NB);
+    const int tiles_m = a.M / MB, tiles = tiles_m * (a.N / NB);
+    int64_t need = 0;
+    const int64_t nz = whole_nz<FR, MB, NB>(a, cus, &need);
+    if (ws_query) {
+        *ws_query = need;
+        return 1;
+    }
+    const bool ws_ok = a.ws != nullptr && a.ws_floats >= need && ctn_aligned16(a.ws);
     const void* fn = reinterpret_cast<const void*>(&gemm_nt_whole_kernel<BWD, FR, WM, WN, NWM, NWN>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 0;
-    hipLaunchKernelGGL((gemm_nt_whole_kernel<BWD, FR, WM, WN, NWM, NWN>), dim3(a.M / MB, a.N / NB, (unsigned)nz), dim3(WNT), shm, s, a);
+    hipLaunchKernelGGL((gemm_nt_whole_kernel<BWD, FR, WM, WN, NWM, NWN>), dim3(a.M / MB, a.N / NB, (unsigned)nz), dim3(WNT), shm, s, a, ws_ok);
+    if (ws_ok)
+        hipLaunchKernelGGL((gemm_nt_whole_reduce_kernel<WM, WN, NWM, NWN>), dim3(MB * NB / 256 + MB / 64, tiles), dim3(256), 0, s, a,
+                           (int)nz, tiles_m, tiles);
     ++whole_launches;
     return 1;
 }
@@ -446,14 +573,19 @@ int launch_whole(const ctn_gemm_nt_args& a, hipStream_t s, int cus) {
 
 extern "C" int64_t ctn_gemm_nt_whole_launches(void) { return whole_launches.load(); }
 
-// Launches the whole-output kernel when CTN_NT_WHOLE=1 is set in the environment (read at every call) and the call is
-// one of its two forms; returns 0 (nothing launched) otherwise, and the caller goes on to the tile-per-block kernels.
-int ctn_gemm_nt_whole_try(const ctn_gemm_nt_args& a, hipStream_t s) {
+// Launches the whole-output kernel when the call is one of its two forms (CTN_NT_WHOLE in the environment, read at
+// every call: 0 never, 2 the bottleneck form only, 3 the heads' form only); returns 0 (nothing launched) otherwise, and
+// the caller goes on to the tile-per-block kernels.  With ws_query the call launches nothing and reports the workspace
+// the launch would use.
+int ctn_gemm_nt_whole_try(const ctn_gemm_nt_args& a, hipStream_t s, int64_t* ws_query) {
     const char* const on = getenv("CTN_NT_WHOLE");
-    if (on == nullptr || on[0] != '1') return 0;
+    const char mode = on ? on[0] : '1';
+    if (mode < '1' || mode > '3') return 0;
+    const bool want_bwd = mode != '3', want_heads = mode != '2';
     if (a.arith != CTN_ARITH_DEFAULT && a.arith != CTN_ARITH_BF16X3) return 0;
     if (a.a_rowsum_b || a.wdot_sums) return 0;
     const bool bwd = (a.aflags & CTN_XF_NORMBWD) != 0;
+    if (bwd ? !want_bwd : !want_heads) return 0;
     if ((a.aflags & ~CTN_XF_NORMBWD) || (a.bflags & ~(CTN_XF_PRELU | CTN_XF_NORM))) return 0;
     if (bwd && (a.bflags != 0 || a.a_sst != 0 || a.M1 != a.M || !a.a_alpha)) return 0;
     if (!bwd && (a.bflags & CTN_XF_NORM) && a.b_sst != 0) return 0;          // per-frame statistics: the tile kernels
@@ -467,22 +599,25 @@ int ctn_gemm_nt_whole_try(const ctn_gemm_nt_args& a, hipStream_t s) {
     if (!ok(a.A, a.lda, a.abs_, a.M1) || !ok(a.Ab, a.ldab, a.abbs, a.M - a.M1) || !ok(a.B, a.ldb, a.bbs, a.N)) return 0;
     if (bwd && !ok(a.A2, a.lda2, a.a2bs, a.M)) return 0;
     if (a.M1 % 128 != 0 && a.M1 != a.M) return 0;              // a staging thread's rows lie 128 apart: keep the split on that grid
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        return n;
-    }();
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
     // enough stages to give every CU work: below that the tile kernels' finer split does better
     if (bwd) {
         const int64_t nstages = (int64_t)a.batch * ((a.T + 31) / 32);
         if (a.M % 256 != 0 || a.N != 128) return 0;
         if (nstages < 4 * (int64_t)(cus / (a.M / 256))) return 0;
-        return launch_whole<true, 32, 2, 2, 4, 2>(a, s, cus);
+        return launch_whole<true, 32, 2, 2, 4, 2>(a, s, cus, ws_query);
     }
     const int64_t nstages = (int64_t)a.batch * ((a.T + 15) / 16);
     if (a.M != 256 || a.N % 256 != 0) return 0;
     if (nstages < 8 * (int64_t)(cus / (a.N / 256))) return 0;
-    return launch_whole<false, 16, 4, 2, 2, 4>(a, s, cus);
+    return launch_whole<false, 16, 4, 2, 2, 4>(a, s, cus, ws_query);
+}
+
+extern "C" int64_t ctn_gemm_nt_ws_floats(const ctn_gemm_nt_args* args) {
+    int64_t need = 0;
+    if (args == nullptr || !ctn_gemm_nt_whole_try(*args, nullptr, &need)) return 0;
+    return need;
 }

@@ -690,7 +690,28 @@ def gemm_nt(M, N, T, batch, A, B, Cout, ldc, *, Ab=None, M1=None, C2=None, ldc2=
         a.wdot2, a.ldwd2 = _ptr(wdot2), wdot2.stride(0)
     a.C, a.ldc = _ptr(Cout), ldc
     a.C2, a.ldc2 = _ptr(C2), ldc2
-    _lib.check(lib.ctn_gemm_nt(C.byref(a), _stream()), "ctn_gemm_nt")
+    stream = _stream()
+    need = lib.ctn_gemm_nt_ws_floats(C.byref(a))
+    if need > 0:
+        ws = _nt_workspace(need, Cout.device, stream)
+        if ws is not None:                     # (tests replace _nt_workspace to reach the atomics route)
+            a.ws, a.ws_floats = _ptr(ws), ws.numel()
+    _lib.check(lib.ctn_gemm_nt(C.byref(a), stream), "ctn_gemm_nt")
+
+
+_nt_ws = {}
+
+
+def _nt_workspace(need, device, stream):
+    """The partial-output workspace of ctn_gemm_nt's whole-output kernels: one buffer per (device, stream), since calls
+    on different streams may run at the same time; grown on demand.  Under stream capture the buffer comes from the
+    graph's pool like every activation of the captured pass, and stays referenced here for the graph's replays."""
+    key = (device.index, stream)
+    ws = _nt_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=device, dtype=torch.float32)
+        _nt_ws[key] = ws
+    return ws
 
 
 def heads_bwd_usable(M1, M2, H, T, stat, y2=None):

@@ -101,3 +101,32 @@ def test_strided_views_and_accumulation():
     torch.cuda.synchronize()
     assert_close(C1, 2 * torch.einsum("bmt,bnt->mn", A1.double(), y.double()), TOL, "C1")
     assert_close(C2, 2 * torch.einsum("bmt,bnt->mn", A2.double(), y.double()), TOL, "C2")
+
+
+def test_partials_through_the_workspace_are_added_in_a_fixed_order(monkeypatch):
+    """With a workspace the blocks store their partial outputs and a second launch adds them in block order: two runs
+    give the same bits (the atomics route differs from run to run in the last place), and both routes agree."""
+    from speech_amd import ops
+    M1 = M2 = 128
+    N, T, B = 512, 3999, 6
+    f = lambda t: t.float().to(dev())
+    A1, A2, y = act(rnd((B, M1, T), 170)), act(rnd((B, M2, T), 171)), act(rnd((B, N, T), 172) + 0.1)
+    alpha = f(torch.tensor([0.2], dtype=torch.float64))
+    gamma, beta = f(1 + 0.2 * rnd((N,), 173)), f(0.2 * rnd((N,), 174))
+    st = make_stat(torch.full((B, 1, 1), 0.05, dtype=torch.float64), torch.full((B, 1, 1), 1.3, dtype=torch.float64), False)
+
+    def run():
+        C1, C2 = torch.zeros(M1, N, device=dev()), torch.zeros(M2, N, device=dev())
+        r1, r2 = torch.zeros(M1, device=dev()), torch.zeros(M2, device=dev())
+        ops.gemm_nt(M1 + M2, N, T, B, A1, y, C1, N, Ab=A2, M1=M1, C2=C2, ldc2=N, a_rowsum=r1, a_rowsum2=r2,
+                    bflags=ops.XF_PRELU | ops.XF_NORM, b_alpha=alpha, b_stat=st, b_gamma=gamma, b_beta=beta)
+        torch.cuda.synchronize()
+        return C1, C2, r1, r2
+
+    first, second = run(), run()
+    for x, y_ in zip(first, second):
+        assert torch.equal(x, y_)
+    monkeypatch.setattr(ops, "_nt_workspace", lambda *a: None)
+    third = run()
+    for x, y_ in zip(first, third):
+        assert_close(x, y_.double().cpu(), TOL, "atomics route")

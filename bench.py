@@ -146,7 +146,7 @@ def instrumented_step(trainer, mixture, sources, full_step=True):
     wrapped["dw_fwd"] = wrap("dw_fwd", dw_fwd_work)
     wrapped["dw_bwd"] = wrap("dw_bwd", dw_bwd_work)
     run = trainer.step if full_step else trainer.forward_backward
-    # per-kernel timing needs eager launches on ONE stream (two sub-batch streams overlap kernels, which makes a
+    # per-kernel timing needs eager launches on ONE stream (sub-batch streams, when asked for, overlap kernels, which makes a
     # kernel's own duration meaningless); the work is the same full per-GPU batch
     graph_mode, trainer.use_graph = trainer.use_graph, False
     n_streams, trainer.n_streams = trainer.n_streams, 1
@@ -591,7 +591,7 @@ def main():
             peak = executed_peak(pieces)
             rows = {}
             for key, kernel in (("gemm_nn", "gemm_nn_fast_kernel (pointwise conv fwd + dgrad)"),
-                                ("gemm_nt", "gemm_nt_fast_kernel (weight gradients)")):
+                                ("gemm_nt", "gemm_nt_whole_kernel + its reduction, gemm_nt_fast_kernel (weight gradients)")):
                 g = pr[key]
                 rate = g["work"] / (g["ms"] * 1e-3) / 1e12
                 row = dict(bound="mfma", kernel=kernel, achieved=round(rate, 2), peak=round(peak, 1), unit="TFLOP/s",

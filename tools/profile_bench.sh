@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes of bench.py whose summaries go to profiles/ (run on the GPU box through gpurun, from the repo root):
 #   1. kernel trace + stats of the profiled command (eager, one stream: the mode in which a kernel's duration is its own)
-#   2. kernel trace + stats of the default mode (graph replay, two sub-batch streams)
+#   2. kernel trace + stats of the default mode (graph replay, one stream)
 #   3. / 4. PMC passes, one counter each: FETCH_SIZE, WRITE_SIZE
 # Outputs land under gpurun_out/prof/.
 set -e

@@ -1,5 +1,5 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE counter_collection CSVs).
-FETCH_SIZE (KB) is doubled: on gfx950 it tallies the 128-byte requests of wide streaming reads at 64 bytes.
+FETCH_SIZE (KB) is doubled: on gfx950 it tallies the 128-byte requests of wide streaming reads at 64 bytes (EXACT_FETCH lists the kernels whose requests are 64 bytes wide and need no correction).
 Besides the per-kernel averages the summary carries `sequence`: for the GEMM and depthwise kernel families the bytes of
 every launch of ONE pass in launch order (averaged over the passes of the run), so that bench.py can attribute traffic
 to the launch shapes of a residual layer although several shapes share one kernel instance.
@@ -20,6 +20,13 @@ def load(path, cname):
 
 
 FAMILIES = {"gemm_nn": "gemm_nn", "gemm_nt": "gemm_nt", "dw_fwd": "dw_fwd", "dw_bwd": "dw_bwd"}
+# kernels whose read requests are 64 bytes wide (four lanes of a row): FETCH_SIZE tallies them as they are -- for the
+# heads' whole-output weight gradient TCC_EA0_RDREQ x 64 bytes equals the operands' 524 MB at batch 32 -- so no doubling
+EXACT_FETCH = ("gemm_nt_whole_kernel<false, 16",)
+
+
+def fetch_scale(name):
+    return 1.0 if any(k in name for k in EXACT_FETCH) else 2.0
 
 
 def load_sequence(path, cname, scale):
@@ -28,10 +35,14 @@ def load_sequence(path, cname, scale):
     with open(path) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] == cname:
-                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"]) * 1024.0 * scale))
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"],
+                             float(r["Counter_Value"]) * 1024.0 * (fetch_scale(r["Kernel_Name"]) if scale == 2.0 else scale)))
     rows.sort()
     seq = collections.defaultdict(list)
     for _, name, v in rows:
+        if "gemm_nt_whole_reduce" in name and seq["gemm_nt"]:
+            seq["gemm_nt"][-1] += v          # second launch of the same ctn_gemm_nt call: one entry per call
+            continue
         for fam, key in FAMILIES.items():
             if key in name:
                 seq[fam].append(v)
@@ -55,7 +66,7 @@ out = {}
 for k in sorted(fe, key=lambda k: -fe[k][1]):
     n, v = fe[k]
     wn, wv = wr.get(k, [0, 0.0])
-    rd = 2.0 * v / n * 1024.0
+    rd = fetch_scale(k) * v / n * 1024.0
     wb = wv / max(1, wn) * 1024.0
     out[k] = dict(launches=n, read_bytes_per_launch=rd, write_bytes_per_launch=wb, hbm_bytes_per_launch=rd + wb)
 for k, d in list(out.items())[:16]:
@@ -73,8 +84,9 @@ if len(sys.argv) > 3:
                    "--no-roofline (default arithmetic: three bf16 pieces)",
         "collection": "two rocprofv3 --pmc passes of the same command (FETCH_SIZE, WRITE_SIZE), tools/profile_bench.sh; "
                       "FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16-byte-per-lane streaming reads at 64 "
-                      "bytes); kernels that read 4 bytes per lane (maskdecode_*, encoder_bwd) are over-counted by that "
-                      "correction",
+                      "bytes), except for gemm_nt_whole_kernel<false, 16, ...>, whose requests are 64 bytes wide and "
+                      "tallied as they are; kernels that read 4 bytes per lane (maskdecode_*, encoder_bwd) are "
+                      "over-counted by the correction",
         "passes": passes,
         "kernels": out,
         "sequence": sequence,

@@ -99,8 +99,9 @@ def test_strided_views_and_accumulation():
     for _ in range(2):
         ops.gemm_nt(M1 + M2, N, T, B, A1, y, C1, N, Ab=A2, M1=M1, C2=C2, ldc2=N)
     torch.cuda.synchronize()
-    assert_close(C1, 2 * torch.einsum("bmt,bnt->mn", A1.double(), y.double()), TOL, "C1")
-    assert_close(C2, 2 * torch.einsum("bmt,bnt->mn", A2.double(), y.double()), TOL, "C2")
+    A1c, A2c, yc = A1.double().cpu(), A2.double().cpu(), y.double().cpu()
+    assert_close(C1, 2 * torch.einsum("bmt,bnt->mn", A1c, yc), TOL, "C1")
+    assert_close(C2, 2 * torch.einsum("bmt,bnt->mn", A2c, yc), TOL, "C2")
 
 
 def test_partials_through_the_workspace_are_added_in_a_fixed_order(monkeypatch):

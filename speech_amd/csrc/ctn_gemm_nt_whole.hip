@@ -81,7 +81,11 @@ typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
         asm volatile("" ::: "memory");                      \
     } while (0)
 
-// which waves run a stage's two halves in the other order (0: none; 1: waves 4..7; 2: odd waves)
+// Pipeline settings, fixed per form by measurement (the macros exist for diagnostic builds):
+//   WH_IP_*:     row tiles of a wave whose accumulations alternate (1: two independent chains, 2: four)
+//   WH_AORDER_*: where the first half of the waves requests the next operands (0: in front of its matrix
+//                instructions, the stage after the current one; 1: behind its stores, two stages ahead)
+//   WH_SHIFT:    which waves run a stage's two halves in the other order (0: none; 1: waves 4..7; 2: odd waves; 3: all)
 #ifndef WH_IP_BWD
 #define WH_IP_BWD 1
 #endif
@@ -217,7 +221,7 @@ void gemm_nt_whole_kernel(const ctn_gemm_nt_args a, const bool ws_ok) {
     };
     // stages bz, bz + nz, ...: (batch element, stage inside it) of the next request, advanced without divisions
     int nb = bz / spb, ns = bz % spb;
-    auto fetch = [&](const int, Stage& st) {
+    auto fetch = [&](const int /* stage index: the cursor below keeps it */, Stage& st) {
         const bool live = nb < a.batch;
         const int b = live ? nb : 0;
         const int t0 = live ? ns * FR : T;

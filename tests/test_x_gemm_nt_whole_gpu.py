@@ -131,3 +131,28 @@ def test_partials_through_the_workspace_are_added_in_a_fixed_order(monkeypatch):
     third = run()
     for x, y_ in zip(first, third):
         assert_close(x, y_.double().cpu(), TOL, "atomics route")
+
+
+def test_bottleneck_form_is_reproducible():
+    """Two runs of the norm-backward form through the workspace give the same bits in the weight and bias gradients
+    (the PReLU-slope gradient goes through fp64 atomics and may differ in its last place)."""
+    from speech_amd import ops
+    H, NB, T, B = 512, 128, 3999, 6
+    f = lambda t: t.float().to(dev())
+    dn, y, Bm = act(rnd((B, H, T), 180)), act(rnd((B, H, T), 181) + 0.2), act(rnd((B, NB, T), 182))
+    alpha, gamma = f(torch.tensor([0.2], dtype=torch.float64)), f(1 + 0.2 * rnd((H,), 183))
+    st = make_stat(0.05 * rnd((B, 1, 1), 184), 1.0 + 0.1 * rnd((B, 1, 1), 185).abs(), False)
+    st.c1, st.c2 = f(1e-3 * rnd((B,), 186)), f(1e-3 * rnd((B,), 187))
+
+    def run():
+        dW, db = torch.zeros(H, NB, device=dev()), torch.zeros(H, device=dev())
+        da = torch.zeros(ops._lib.STAT_SLOTS, device=dev(), dtype=torch.float64)
+        ops.gemm_nt(H, NB, T, B, dn, Bm, dW, NB, aflags=ops.XF_NORMBWD, A2=y, a_alpha=alpha, a_stat=st, a_gamma=gamma,
+                    a_rowsum=db, a_dalpha=da)
+        torch.cuda.synchronize()
+        return dW, db, da.sum()
+
+    runs = [run() for _ in range(3)]
+    for dW, db, da in runs[1:]:
+        assert torch.equal(dW, runs[0][0]) and torch.equal(db, runs[0][1])
+        assert abs(float(da - runs[0][2])) <= 1e-9 * abs(float(runs[0][2])) + 1e-12

@@ -377,8 +377,9 @@ typedef struct {
 
 int ctn_gemm_nt(const ctn_gemm_nt_args* args, void* stream);
 
-/* The whole-output kernels of ctn_gemm_nt: for the two weight-gradient shapes of a residual layer (M = 256 against N a
- * multiple of 256; the NORMBWD operand with M a multiple of 256 against N = 128), three-piece arithmetic, global norm
+/* The whole-output kernels of ctn_gemm_nt: for the two weight-gradient shapes of a residual layer and the mask
+ * convolution's (M = 256 against N a multiple of 256; M a multiple of 256 against N = 128, with or without the NORMBWD
+ * operand), three-piece arithmetic, global norm
  * statistics and enough frames to give every CU four to eight stages, one 512-thread block per CU keeps a 256 x 256 or
  * 256 x 128 output in its accumulators and every operand element is fetched, transformed and split once.  With a
  * workspace (fields ws / ws_floats) the blocks store their partial outputs and a second launch adds them in a fixed

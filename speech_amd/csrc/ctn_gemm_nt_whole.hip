@@ -614,6 +614,13 @@ int ctn_gemm_nt_whole_try(const ctn_gemm_nt_args& a, hipStream_t s, int64_t* ws_
         if (nstages < 4 * (int64_t)(cus / (a.M / 256))) return 0;
         return launch_whole<true, 32, 2, 2, 4, 2>(a, s, cus, ws_query);
     }
+    if (a.M % 256 == 0 && a.N == 128) {                        // tall outputs (the mask convolution, 1024 x 128: 266 us against 310)
+        const int64_t nstages = (int64_t)a.batch * ((a.T + 31) / 32);
+        if (nstages < 4 * (int64_t)(cus / (a.M / 256))) return 0;
+        return launch_whole<false, 32, 2, 2, 4, 2>(a, s, cus, ws_query);
+    }
+    // (128 x 512 outputs -- a single head, the entry bottleneck -- stay with the tile kernels: a 128 x 256 block form
+    // of this kernel measured 154 - 165 us against their 145)
     const int64_t nstages = (int64_t)a.batch * ((a.T + 15) / 16);
     if (a.M != 256 || a.N % 256 != 0) return 0;
     if (nstages < 8 * (int64_t)(cus / (a.N / 256))) return 0;

@@ -141,3 +141,9 @@ def test_bottleneck_form_indices(H, NB, T, B):
     ld = r4(T)
     r = audit(True, 32, 2, 2, 4, 2, H, NB, T, B, H, ld, ld, ld, ld, H, 0, NB, H * ld, 0, H * ld, NB * ld)
     assert r["need"] == 8454144 and r["shm"] == 147456
+
+
+@pytest.mark.parametrize("M,N,T,B", [(1024, 128, 3999, 6), (1024, 128, 3999, 32), (512, 128, 4100, 9)])
+def test_tall_form_indices(M, N, T, B):
+    ld = r4(T)
+    audit(False, 32, 2, 2, 4, 2, M, N, T, B, M, ld, ld, ld, ld, M, 0, N, M * ld, 0, 0, N * ld)

@@ -22,7 +22,7 @@ def whole_output_kernels(monkeypatch):
 
 
 @pytest.mark.parametrize("M1,M2,N,T,B", [(128, 128, 512, 3999, 5), (128, 128, 256, 8191, 4), (256, 0, 512, 4100, 4),
-                                          (128, 128, 512, 4001, 5)])
+                                          (128, 128, 512, 4001, 5), (1024, 0, 128, 3999, 6)])
 def test_heads_form(M1, M2, N, T, B):
     from speech_amd import ops
     f = lambda t: t.float().to(dev())
